@@ -1,0 +1,193 @@
+/*
+ * rtx_hip.h — C ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * This is the boundary a host renderer binds instead of the reference's optional GPU
+ * backend  raytracer::cuda::GPUPathTracer  (engine/cuda/cuda_api.hpp:72-110).  Unlike that
+ * backend it carries the *whole* scene (triangles, boxes, quad/disk/point lights, textures,
+ * environment map) and keeps geometry in double precision so that the closest-hit
+ * validation entry point sees the same bits as the CPU renderer.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no exceptions cross the boundary
+ *   - every function returns 0 on success and a negative rtx_status otherwise;
+ *     rtx_last_error() returns a thread-local message for the last failure
+ *   - the caller owns every input array (copied during rtx_upload_scene) and every output
+ *     buffer; the library owns device memory and frees it in rtx_destroy
+ *   - one host thread per context; calls on one context are synchronous unless stated
+ *   - film layout: RGB interleaved floats, pixel (x, y) at (y*width + x)*3, y = 0 is the
+ *     BOTTOM row — the convention of Image::set_pixel / GPUPathTracer::render
+ *     (engine/renderer.hpp:60-69, engine/main.cpp:394-397); values are linear averaged
+ *     radiance, no exposure / tone map / gamma (engine/main.cpp:399-427 applies those)
+ */
+#ifndef RTX_HIP_H
+#define RTX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rtx_status {
+  RTX_OK = 0,
+  RTX_ERR_INVALID_ARGUMENT = -1,
+  RTX_ERR_NO_DEVICE = -2,
+  RTX_ERR_HIP = -3,
+  RTX_ERR_NOT_READY = -4,      /* render before upload_scene / set_camera */
+  RTX_ERR_UNSUPPORTED = -5,    /* e.g. use_mnee = 1 */
+  RTX_ERR_OUT_OF_MEMORY = -6
+} rtx_status;
+
+/* ---- scene description: the fields of the reference's scene objects, verbatim ---- */
+
+/* Sphere (engine/sphere.hpp:55-61) */
+typedef struct rtx_sphere { double center[3]; double radius; int32_t material_id; int32_t pad_; } rtx_sphere;
+/* Plane (engine/primitives.hpp:24-30); `normal` is the stored, already normalised member */
+typedef struct rtx_plane { double point[3]; double normal[3]; int32_t material_id; int32_t pad_; } rtx_plane;
+/* Triangle (engine/primitives.hpp:68-73) */
+typedef struct rtx_triangle { double v0[3], v1[3], v2[3]; int32_t material_id; int32_t pad_; } rtx_triangle;
+/* Box (engine/primitives.hpp:134-140) */
+typedef struct rtx_box { double box_min[3], box_max[3]; int32_t material_id; int32_t pad_; } rtx_box;
+/* PointLight (engine/scene.hpp:45-50) */
+typedef struct rtx_point_light { double position[3]; double intensity[3]; } rtx_point_light;
+/* QuadLight (engine/primitives.hpp:219-234): every member, including the derived ones */
+typedef struct rtx_quad_light { double corner[3], edge_u[3], edge_v[3], normal[3], emission[3]; double area; } rtx_quad_light;
+/* DiskLight (engine/primitives.hpp:321-344) */
+typedef struct rtx_disk_light { double center[3], normal[3]; double radius; double emission[3]; double area; double tangent[3], bitangent[3]; } rtx_disk_light;
+
+/* MaterialType (engine/material.hpp:29-33) */
+enum { RTX_MAT_LAMBERTIAN = 0, RTX_MAT_METAL = 1, RTX_MAT_DIELECTRIC = 2 };
+/* TextureType (engine/texture.hpp, Texture::type) */
+enum { RTX_TEX_SOLID = 0, RTX_TEX_CHECKER = 1, RTX_TEX_IMAGE = 2 };
+
+/* Material (engine/material.hpp:48-66), the members the path tracer reads */
+typedef struct rtx_material {
+  int32_t type;            /* RTX_MAT_* */
+  int32_t has_texture;     /* Material::has_texture */
+  double albedo[3];
+  double emission[3];
+  double fuzz;
+  double refraction_index;
+  int32_t tex_type;        /* RTX_TEX_* (Texture::type) */
+  int32_t tex_image;       /* index into rtx_scene_desc::images, or -1 */
+  double tex_color1[3];
+  double tex_color2[3];
+  double tex_scale;
+} rtx_material;
+
+/* Texture image data (engine/texture.hpp:196-199): 8-bit RGB, row 0 = top */
+typedef struct rtx_image { const uint8_t* rgb; int32_t width, height; } rtx_image;
+
+/* EnvironmentMap (engine/texture.hpp:352-362): float RGB texels, row 0 = top (theta = 0) */
+typedef struct rtx_environment { const float* rgb; int32_t width, height; double intensity; double rotation; /* radians */ } rtx_environment;
+
+typedef struct rtx_scene_desc {
+  const rtx_sphere* spheres;           size_t n_spheres;
+  const rtx_plane* planes;             size_t n_planes;
+  const rtx_triangle* triangles;       size_t n_triangles;
+  const rtx_box* boxes;                size_t n_boxes;
+  const rtx_point_light* point_lights; size_t n_point_lights;
+  const rtx_quad_light* quad_lights;   size_t n_quad_lights;
+  const rtx_disk_light* disk_lights;   size_t n_disk_lights;
+  const rtx_material* materials;       size_t n_materials;
+  const rtx_image* images;             size_t n_images;
+  const rtx_environment* environment;  /* NULL when the scene has none */
+} rtx_scene_desc;
+
+/* Camera (engine/scene.hpp:55-59): the four stored vectors */
+typedef struct rtx_camera { double origin[3], lower_left_corner[3], horizontal[3], vertical[3]; } rtx_camera;
+
+enum { RTX_PRECISION_F32 = 0, RTX_PRECISION_F64 = 1 };
+enum { RTX_PIPELINE_AUTO = 0, RTX_PIPELINE_FUSED = 1, RTX_PIPELINE_WAVEFRONT = 2 };
+
+/* Renderer::Settings (engine/renderer.hpp:101-133), PathTrace mode members, plus what a
+ * GPU backend needs in addition (seed, precision, pipeline, row sharding). */
+typedef struct rtx_settings {
+  int32_t width, height;
+  int32_t samples_per_pixel;
+  int32_t max_depth;
+  int32_t use_nee, use_mis, use_mnee;      /* use_mnee != 0 -> RTX_ERR_UNSUPPORTED */
+  int32_t use_background_gradient;
+  double background_color[3], background_top[3], background_bottom[3];
+  uint32_t seed;
+  int32_t precision;                        /* RTX_PRECISION_* */
+  int32_t pipeline;                         /* RTX_PIPELINE_* */
+  /* Row sharding: this context renders rows y with  y % shard_count == shard_index.
+   * shard_count = 1 renders the whole film. */
+  int32_t shard_index, shard_count;
+} rtx_settings;
+
+typedef struct rtx_stats {
+  uint64_t samples;          /* camera paths started */
+  uint64_t rays_closest;     /* closest-hit queries executed */
+  uint64_t rays_shadow;      /* shadow (any-hit) queries executed */
+  uint64_t segments;         /* path vertices shaded */
+  double seconds_render;     /* device time of the render kernels (HIP events) */
+  double seconds_total;      /* wall time of the call */
+  uint32_t kernel_launches;
+  uint32_t pipeline_used;    /* RTX_PIPELINE_FUSED or _WAVEFRONT */
+} rtx_stats;
+
+/* One closest-hit result: the members of hit_record (core/hit.h:20-29) that identify the
+ * hit, plus which primitive won. */
+enum { RTX_PRIM_SPHERE = 0, RTX_PRIM_PLANE = 1, RTX_PRIM_TRIANGLE = 2, RTX_PRIM_BOX = 3, RTX_PRIM_QUAD_LIGHT = 4, RTX_PRIM_DISK_LIGHT = 5 };
+typedef struct rtx_hit {
+  int32_t hit, prim_type, prim_index, material_id, front_face, pad_;
+  double t, point[3], normal[3], u, v;
+} rtx_hit;
+
+typedef struct rtx_ctx rtx_ctx;
+
+/* Replaces raytracer::cuda::test_cuda() (engine/cuda/cuda_api.hpp:17, cuda_test.cu:25-81):
+ * runs a trivial kernel on the device and checks its output. */
+int rtx_selftest(int device_id);
+
+/* Replaces GPUPathTracer::GPUPathTracer() / ~GPUPathTracer() (cuda_api.hpp:74-75). */
+int rtx_create(rtx_ctx** out_ctx, int device_id);
+int rtx_destroy(rtx_ctx* ctx);
+
+/* Replaces GPUPathTracer::upload_scene (cuda_api.hpp:84-89; cuda_pathtracer.cu:234-318).
+ * Copies the description, builds both BVHs (the reference-order binary tree of
+ * engine/bvh.hpp:148-218 for validation, and the wide one the integrator traverses) and
+ * the environment-map sampling tables (engine/texture.hpp:403-473). */
+int rtx_upload_scene(rtx_ctx* ctx, const rtx_scene_desc* scene);
+
+/* Replaces GPUPathTracer::set_camera (cuda_api.hpp:99).  Takes the vectors of an already
+ * constructed Camera, so there is no ordering constraint against the settings. */
+int rtx_set_camera(rtx_ctx* ctx, const rtx_camera* camera);
+
+/* Replaces GPUPathTracer::set_settings + GPUPathTracer::render (cuda_api.hpp:94,105;
+ * cuda_pathtracer.cu:320-379) and, on the CPU side, the PathTrace branch of
+ * Renderer::render (engine/renderer.cpp:378-449).  Synchronous.  `out_rgb` is host memory,
+ * width*height*3 floats for shard_count == 1, otherwise rows_of_shard*width*3 floats with the
+ * shard's rows packed bottom-up.  `stats` may be NULL. */
+int rtx_render(rtx_ctx* ctx, const rtx_settings* settings, float* out_rgb, rtx_stats* stats);
+
+/* Same, but `d_out_rgb` is DEVICE memory on the context's device and the work is enqueued
+ * on `hip_stream` (a hipStream_t, NULL = the context's own stream).  Returns after the
+ * kernels have finished (stats need the device counters). */
+int rtx_render_device(rtx_ctx* ctx, const rtx_settings* settings, void* d_out_rgb, void* hip_stream, rtx_stats* stats);
+
+/* Closest-hit validation entry point: the GPU counterpart of Scene::hit
+ * (engine/scene.hpp:574-674) in double precision on the reference-order BVH.
+ * rays8: n records of 8 doubles (origin xyz, direction xyz, t_min, t_max), host memory. */
+int rtx_trace_closest(rtx_ctx* ctx, const double* rays8, size_t n, rtx_hit* out_hits);
+
+/* Same query through the wide BVH and float/double kernels the integrator uses
+ * (precision = RTX_PRECISION_*); for measuring ID agreement of the fast path. */
+int rtx_trace_closest_fast(rtx_ctx* ctx, const double* rays8, size_t n, int precision, rtx_hit* out_hits);
+
+/* Number of rows a shard owns: |{ y in [0,height) : y % shard_count == shard_index }|. */
+int rtx_shard_rows(int height, int shard_index, int shard_count);
+
+/* BVH statistics of the uploaded scene (0 when there is no bounded primitive). */
+typedef struct rtx_bvh_info { uint64_t ref_nodes, ref_prims, wide_nodes, wide_bytes; double build_seconds; } rtx_bvh_info;
+int rtx_get_bvh_info(rtx_ctx* ctx, rtx_bvh_info* out);
+
+const char* rtx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_HIP_H */

@@ -1,0 +1,1075 @@
+// TEST INFRASTRUCTURE ONLY — see pt_oracle.h.
+//
+// CPU restatement, in double precision, of the reference's path-tracing hot path.  Each
+// routine names the reference lines it follows.  Arithmetic is written in the reference's
+// operand order and the file is built with -ffp-contract=off for baseline x86-64, so that
+// (a) closest hits equal the reference's bit for bit and (b) with the mt19937 sampler and
+// one thread, whole films equal the reference's bit for bit.  oracle/_ref/ref_harness
+// (the real reference, built in place) generated the fixtures that pin both claims.
+#include "pt_oracle.h"
+
+#include <omp.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <random>
+#include <vector>
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// ----------------------------------------------------------------------------------------
+// vector arithmetic — core/vec3.c:9-91
+// ----------------------------------------------------------------------------------------
+struct V3 { double x, y, z; };
+inline V3 mk(const double* p) { return {p[0], p[1], p[2]}; }
+inline V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 mul(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3 scale(V3 v, double t) { return {v.x * t, v.y * t, v.z * t}; }
+inline V3 neg(V3 v) { return {-v.x, -v.y, -v.z}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double len2(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+inline double len(V3 v) { return std::sqrt(len2(v)); }
+inline V3 normalize(V3 v) { double l = len(v); if (l > 0.0) return scale(v, 1.0 / l); return v; }
+inline V3 reflect(V3 v, V3 n) { return sub(v, scale(n, 2.0 * dot(v, n))); }
+inline V3 refract(V3 uv, V3 n, double eta) {  // core/vec3.c:69-79
+  double cos_theta = std::fmin(dot(neg(uv), n), 1.0);
+  V3 perp = scale(add(uv, scale(n, cos_theta)), eta);
+  double par = -std::sqrt(std::fabs(1.0 - len2(perp)));
+  return add(perp, scale(n, par));
+}
+inline V3 lerp(V3 a, V3 b, double t) { return add(scale(a, 1.0 - t), scale(b, t)); }
+
+struct Ray { V3 o, d; };
+inline V3 at(const Ray& r, double t) { return add(r.o, scale(r.d, t)); }  // core/ray.c:12
+
+// hit_record (core/hit.h:20-29) without the tangent (only normal maps read it), plus the
+// identity of the primitive that produced it.
+struct Hit {
+  V3 p{0, 0, 0}, n{0, 0, 0};
+  double t = 0, u = 0, v = 0;
+  bool front = false;
+  int mat = 0;
+  int ptype = -1, pidx = -1;
+};
+inline void face_normal(Hit& h, const Ray& r, V3 outward) {  // core/hit.c:21-24
+  h.front = dot(r.d, outward) < 0;
+  h.n = h.front ? outward : neg(outward);
+}
+
+// ----------------------------------------------------------------------------------------
+// scene storage
+// ----------------------------------------------------------------------------------------
+struct Box6 { V3 lo{1e30, 1e30, 1e30}, hi{-1e30, -1e30, -1e30}; };  // AABB, engine/bvh.hpp:25-27
+inline void grow(Box6& b, V3 p) {  // engine/bvh.hpp:69-76
+  b.lo.x = std::fmin(b.lo.x, p.x); b.lo.y = std::fmin(b.lo.y, p.y); b.lo.z = std::fmin(b.lo.z, p.z);
+  b.hi.x = std::fmax(b.hi.x, p.x); b.hi.y = std::fmax(b.hi.y, p.y); b.hi.z = std::fmax(b.hi.z, p.z);
+}
+inline void grow(Box6& b, const Box6& o) { grow(b, o.lo); grow(b, o.hi); }
+inline V3 centroid(const Box6& b) { return {(b.lo.x + b.hi.x) * 0.5, (b.lo.y + b.hi.y) * 0.5, (b.lo.z + b.hi.z) * 0.5}; }
+
+struct PrimRef { Box6 box; int index = 0, type = 0; };
+struct Node { Box6 box; int left = -1, right = -1, first = 0, count = 0; };
+
+struct EnvMap {
+  std::vector<float> texel;
+  int w = 0, h = 0;
+  double intensity = 1.0, rotation = 0.0;
+  std::vector<double> marginal, conditional;
+  double total = 0.0;
+  bool valid() const { return !texel.empty() && w > 0 && h > 0; }
+  bool importance() const { return valid() && !marginal.empty() && total > 0.0; }  // texture.hpp:692-694
+};
+
+}  // namespace
+
+struct orc_scene {
+  std::vector<rtx_sphere> spheres;
+  std::vector<rtx_plane> planes;
+  std::vector<rtx_triangle> tris;
+  std::vector<rtx_box> boxes;
+  std::vector<rtx_point_light> points;
+  std::vector<rtx_quad_light> quads;
+  std::vector<rtx_disk_light> disks;
+  std::vector<rtx_material> mats;
+  std::vector<std::vector<uint8_t>> img_data;
+  std::vector<int> img_w, img_h;
+  EnvMap env;
+  bool has_env = false;
+  std::vector<int> emissive_spheres;  // Scene::get_emissive_spheres, engine/scene.hpp:222-230
+  std::vector<Node> nodes;
+  std::vector<PrimRef> prims;
+};
+
+namespace {
+
+inline bool emissive(const rtx_material& m) {  // material.hpp:115-117
+  return m.emission[0] > 0.0 || m.emission[1] > 0.0 || m.emission[2] > 0.0;
+}
+
+// ----------------------------------------------------------------------------------------
+// BVH build — engine/bvh.hpp:148-218 on the primitive list of engine/scene.hpp:496-533
+// ----------------------------------------------------------------------------------------
+int longest_axis(const Box6& b) {  // bvh.hpp:100-107
+  double dx = b.hi.x - b.lo.x, dy = b.hi.y - b.lo.y, dz = b.hi.z - b.lo.z;
+  if (dx > dy && dx > dz) return 0;
+  if (dy > dz) return 1;
+  return 2;
+}
+
+int build_range(orc_scene& s, int start, int end) {
+  int me = (int)s.nodes.size();
+  s.nodes.emplace_back();
+  Box6 bounds;
+  for (int i = start; i < end; ++i) grow(bounds, s.prims[i].box);
+  s.nodes[me].box = bounds;
+  int count = end - start;
+  if (count <= 2) { s.nodes[me].first = start; s.nodes[me].count = count; return me; }
+  Box6 cb;
+  for (int i = start; i < end; ++i) grow(cb, centroid(s.prims[i].box));
+  int axis = longest_axis(cb);
+  int mid = start + count / 2;
+  // Same library routine as the reference on the same sequence and ordering relation, hence
+  // the same permutation.
+  std::nth_element(s.prims.begin() + start, s.prims.begin() + mid, s.prims.begin() + end,
+                   [axis](const PrimRef& a, const PrimRef& b) {
+                     V3 ca = centroid(a.box), cb2 = centroid(b.box);
+                     if (axis == 0) return ca.x < cb2.x;
+                     if (axis == 1) return ca.y < cb2.y;
+                     return ca.z < cb2.z;
+                   });
+  int l = build_range(s, start, mid);
+  int r = build_range(s, mid, end);
+  s.nodes[me].left = l;
+  s.nodes[me].right = r;
+  return me;
+}
+
+void build_bvh(orc_scene& s) {
+  s.prims.clear(); s.nodes.clear();
+  s.prims.reserve(s.spheres.size() + s.tris.size() + s.boxes.size());
+  for (size_t i = 0; i < s.spheres.size(); ++i) {
+    PrimRef p; p.type = RTX_PRIM_SPHERE; p.index = (int)i;
+    V3 c = mk(s.spheres[i].center); double r = s.spheres[i].radius; V3 rad = {r, r, r};
+    p.box.lo = sub(c, rad); p.box.hi = add(c, rad);
+    s.prims.push_back(p);
+  }
+  for (size_t i = 0; i < s.tris.size(); ++i) {
+    PrimRef p; p.type = RTX_PRIM_TRIANGLE; p.index = (int)i;
+    grow(p.box, mk(s.tris[i].v0)); grow(p.box, mk(s.tris[i].v1)); grow(p.box, mk(s.tris[i].v2));
+    s.prims.push_back(p);
+  }
+  for (size_t i = 0; i < s.boxes.size(); ++i) {
+    PrimRef p; p.type = RTX_PRIM_BOX; p.index = (int)i;
+    p.box.lo = mk(s.boxes[i].box_min); p.box.hi = mk(s.boxes[i].box_max);
+    s.prims.push_back(p);
+  }
+  if (s.prims.empty()) return;
+  s.nodes.reserve(s.prims.size() * 2);
+  build_range(s, 0, (int)s.prims.size());
+}
+
+// ----------------------------------------------------------------------------------------
+// intersection routines
+// ----------------------------------------------------------------------------------------
+bool slab(const Box6& b, const Ray& r, double t_min, double t_max) {  // AABB::hit, bvh.hpp:35-64
+  double inv = 1.0 / r.d.x;
+  double t0 = (b.lo.x - r.o.x) * inv, t1 = (b.hi.x - r.o.x) * inv;
+  if (inv < 0.0) std::swap(t0, t1);
+  t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
+  if (t_max <= t_min) return false;
+  inv = 1.0 / r.d.y;
+  t0 = (b.lo.y - r.o.y) * inv; t1 = (b.hi.y - r.o.y) * inv;
+  if (inv < 0.0) std::swap(t0, t1);
+  t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
+  if (t_max <= t_min) return false;
+  inv = 1.0 / r.d.z;
+  t0 = (b.lo.z - r.o.z) * inv; t1 = (b.hi.z - r.o.z) * inv;
+  if (inv < 0.0) std::swap(t0, t1);
+  t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
+  if (t_max <= t_min) return false;
+  return true;
+}
+
+bool hit_sphere(const rtx_sphere& s, const Ray& r, double t_min, double t_max, Hit& h) {  // sphere.hpp:71-105
+  V3 c = mk(s.center);
+  V3 oc = sub(r.o, c);
+  double a = len2(r.d);
+  double half_b = dot(oc, r.d);
+  double cc = len2(oc) - s.radius * s.radius;
+  double disc = half_b * half_b - a * cc;
+  if (disc < 0) return false;
+  double sq = std::sqrt(disc);
+  double root = (-half_b - sq) / a;
+  if (root < t_min || root > t_max) {
+    root = (-half_b + sq) / a;
+    if (root < t_min || root > t_max) return false;
+  }
+  h.t = root;
+  h.p = at(r, root);
+  V3 on = scale(sub(h.p, c), 1.0 / s.radius);
+  face_normal(h, r, on);
+  h.mat = s.material_id;
+  double theta = std::acos(-on.y);                    // get_sphere_uv, sphere.hpp:26-32
+  double phi = std::atan2(-on.z, on.x) + kPi;
+  h.u = phi / (2.0 * kPi);
+  h.v = theta / kPi;
+  return true;
+}
+
+bool hit_plane(const rtx_plane& pl, const Ray& r, double t_min, double t_max, Hit& h) {  // primitives.hpp:35-60
+  V3 n = mk(pl.normal);
+  double denom = dot(n, r.d);
+  if (std::fabs(denom) < 1e-8) return false;
+  double t = dot(sub(mk(pl.point), r.o), n) / denom;
+  if (t < t_min || t > t_max) return false;
+  h.t = t; h.p = at(r, t);
+  face_normal(h, r, n);
+  h.mat = pl.material_id;
+  return true;  // u, v deliberately left as they were (the reference does not write them)
+}
+
+bool hit_triangle(const rtx_triangle& tr, const Ray& r, double t_min, double t_max, Hit& h) {  // primitives.hpp:78-126
+  V3 v0 = mk(tr.v0);
+  V3 e1 = sub(mk(tr.v1), v0), e2 = sub(mk(tr.v2), v0);
+  V3 hh = cross(r.d, e2);
+  double a = dot(e1, hh);
+  if (std::fabs(a) < 1e-8) return false;
+  double f = 1.0 / a;
+  V3 s = sub(r.o, v0);
+  double u = f * dot(s, hh);
+  if (u < 0.0 || u > 1.0) return false;
+  V3 q = cross(s, e1);
+  double v = f * dot(r.d, q);
+  if (v < 0.0 || u + v > 1.0) return false;
+  double t = f * dot(e2, q);
+  if (t < t_min || t > t_max) return false;
+  h.t = t; h.p = at(r, t);
+  face_normal(h, r, normalize(cross(e1, e2)));
+  h.mat = tr.material_id;
+  h.u = u; h.v = v;
+  return true;
+}
+
+bool hit_box(const rtx_box& b, const Ray& r, double t_min, double t_max, Hit& h) {  // primitives.hpp:153-207
+  double tmin = t_min, tmax = t_max;
+  const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+  for (int ax = 0; ax < 3; ++ax) {
+    double inv = 1.0 / d[ax];
+    double t0 = (b.box_min[ax] - o[ax]) * inv, t1 = (b.box_max[ax] - o[ax]) * inv;
+    if (inv < 0.0) std::swap(t0, t1);
+    tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
+    if (tmax <= tmin) return false;
+  }
+  h.t = tmin; h.p = at(r, tmin);
+  V3 on;
+  const double eps = 1e-4;
+  if (std::fabs(h.p.x - b.box_min[0]) < eps) on = {-1, 0, 0};
+  else if (std::fabs(h.p.x - b.box_max[0]) < eps) on = {1, 0, 0};
+  else if (std::fabs(h.p.y - b.box_min[1]) < eps) on = {0, -1, 0};
+  else if (std::fabs(h.p.y - b.box_max[1]) < eps) on = {0, 1, 0};
+  else if (std::fabs(h.p.z - b.box_min[2]) < eps) on = {0, 0, -1};
+  else on = {0, 0, 1};
+  face_normal(h, r, on);
+  h.mat = b.material_id;
+  return true;
+}
+
+bool hit_quad(const rtx_quad_light& q, const Ray& r, double t_min, double t_max, Hit& h) {  // primitives.hpp:274-313
+  V3 n = mk(q.normal);
+  double denom = dot(n, r.d);
+  if (std::fabs(denom) < 1e-8) return false;
+  V3 corner = mk(q.corner);
+  double t = dot(sub(corner, r.o), n) / denom;
+  if (t < t_min || t > t_max) return false;
+  V3 p = at(r, t);
+  V3 d = sub(p, corner);
+  V3 eu = mk(q.edge_u), ev = mk(q.edge_v);
+  double up = dot(d, eu) / len2(eu), vp = dot(d, ev) / len2(ev);
+  if (up < 0.0 || up > 1.0 || vp < 0.0 || vp > 1.0) return false;
+  h.t = t; h.p = p;
+  face_normal(h, r, n);
+  h.u = up; h.v = vp;
+  return true;
+}
+
+bool hit_disk(const rtx_disk_light& dl, const Ray& r, double t_min, double t_max, Hit& h) {  // primitives.hpp:396-433
+  V3 n = mk(dl.normal);
+  double denom = dot(n, r.d);
+  if (std::fabs(denom) < 1e-8) return false;
+  V3 c = mk(dl.center);
+  double t = dot(sub(c, r.o), n) / denom;
+  if (t < t_min || t > t_max) return false;
+  V3 p = at(r, t);
+  V3 d = sub(p, c);
+  double d2 = len2(d);
+  if (d2 > dl.radius * dl.radius) return false;
+  h.t = t; h.p = p;
+  face_normal(h, r, n);
+  double dist = std::sqrt(d2);
+  h.u = (dist > 1e-8) ? (dot(d, mk(dl.tangent)) / dist + 1.0) * 0.5 : 0.5;
+  h.v = (dist > 1e-8) ? (dot(d, mk(dl.bitangent)) / dist + 1.0) * 0.5 : 0.5;
+  return true;
+}
+
+// Scene::hit — engine/scene.hpp:574-674.  `tmp` plays the reference's temp_rec: it persists
+// across primitive tests, so members a routine does not write (plane/box: u, v) keep the
+// value an earlier successful test left there.
+bool scene_hit(const orc_scene& s, const Ray& r, double t_min, double t_max, Hit& rec) {
+  Hit tmp;
+  bool any = false;
+  double closest = t_max;
+  if (!s.nodes.empty()) {
+    int stack[64];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0 && sp < 64) {
+      int ni = stack[--sp];
+      if (ni < 0 || ni >= (int)s.nodes.size()) continue;
+      const Node& nd = s.nodes[ni];
+      if (!slab(nd.box, r, t_min, closest)) continue;
+      if (nd.count > 0) {
+        for (int i = 0; i < nd.count; ++i) {
+          const PrimRef& pr = s.prims[nd.first + i];
+          bool did = false;
+          switch (pr.type) {
+            case RTX_PRIM_SPHERE: did = hit_sphere(s.spheres[pr.index], r, t_min, closest, tmp); break;
+            case RTX_PRIM_TRIANGLE: did = hit_triangle(s.tris[pr.index], r, t_min, closest, tmp); break;
+            case RTX_PRIM_BOX: did = hit_box(s.boxes[pr.index], r, t_min, closest, tmp); break;
+          }
+          if (did) { any = true; closest = tmp.t; tmp.ptype = pr.type; tmp.pidx = pr.index; rec = tmp; }
+        }
+      } else {
+        if (nd.right >= 0 && sp < 63) stack[sp++] = nd.right;
+        if (nd.left >= 0 && sp < 63) stack[sp++] = nd.left;
+      }
+    }
+  }
+  for (size_t i = 0; i < s.planes.size(); ++i)
+    if (hit_plane(s.planes[i], r, t_min, closest, tmp)) {
+      any = true; closest = tmp.t; tmp.ptype = RTX_PRIM_PLANE; tmp.pidx = (int)i; rec = tmp;
+    }
+  for (size_t i = 0; i < s.quads.size(); ++i)
+    if (hit_quad(s.quads[i], r, t_min, closest, tmp)) {
+      any = true; closest = tmp.t; tmp.ptype = RTX_PRIM_QUAD_LIGHT; tmp.pidx = (int)i;
+      tmp.mat = -1;  // QuadLight::material_id default (primitives.hpp:228), written by QuadLight::hit
+      rec = tmp; rec.mat = -(int)i - 1;  // scene.hpp:657
+    }
+  for (size_t i = 0; i < s.disks.size(); ++i)
+    if (hit_disk(s.disks[i], r, t_min, closest, tmp)) {
+      any = true; closest = tmp.t; tmp.ptype = RTX_PRIM_DISK_LIGHT; tmp.pidx = (int)i;
+      tmp.mat = -1;
+      rec = tmp; rec.mat = -1000 - (int)i;  // scene.hpp:669
+    }
+  return any;
+}
+
+// ----------------------------------------------------------------------------------------
+// environment map — engine/texture.hpp:403-473 (CDFs), :487-549 (lookup), :634-687 (pdf)
+// ----------------------------------------------------------------------------------------
+void build_env_cdf(EnvMap& e) {
+  if (!e.valid()) return;
+  e.marginal.assign(e.h + 1, 0.0);
+  e.conditional.assign((size_t)e.h * (e.w + 1), 0.0);
+  std::vector<double> rows(e.h);
+  for (int y = 0; y < e.h; ++y) {
+    double theta = kPi * (y + 0.5) / e.h;
+    double st = std::sin(theta);
+    double sum = 0.0;
+    size_t off = (size_t)y * (e.w + 1);
+    e.conditional[off] = 0.0;
+    for (int x = 0; x < e.w; ++x) {
+      size_t idx = ((size_t)y * e.w + x) * 3;
+      float r = e.texel[idx], g = e.texel[idx + 1], b = e.texel[idx + 2];
+      double lum = 0.2126 * r + 0.7152 * g + 0.0722 * b;
+      sum += lum * st;
+      e.conditional[off + x + 1] = sum;
+    }
+    if (sum > 0.0) for (int x = 1; x <= e.w; ++x) e.conditional[off + x] /= sum;
+    else for (int x = 1; x <= e.w; ++x) e.conditional[off + x] = (double)x / e.w;
+    rows[y] = sum;
+  }
+  e.marginal[0] = 0.0;
+  for (int y = 0; y < e.h; ++y) e.marginal[y + 1] = e.marginal[y] + rows[y];
+  e.total = e.marginal[e.h];
+  if (e.total > 0.0) for (int y = 1; y <= e.h; ++y) e.marginal[y] /= e.total;
+  else for (int y = 1; y <= e.h; ++y) e.marginal[y] = (double)y / e.h;
+}
+
+V3 env_lookup(const EnvMap& e, V3 direction) {
+  if (!e.valid()) return {0, 0, 0};
+  V3 d = normalize(direction);
+  if (e.rotation != 0.0) {
+    double cr = std::cos(e.rotation), sr = std::sin(e.rotation);
+    double nx = d.x * cr - d.z * sr, nz = d.x * sr + d.z * cr;
+    d.x = nx; d.z = nz;
+  }
+  double phi = std::atan2(d.z, d.x);
+  double theta = std::asin(std::clamp(d.y, -1.0, 1.0));
+  double u = 0.5 + phi / (2.0 * kPi);
+  double v = 0.5 + theta / kPi;
+  double fx = u * e.w - 0.5;
+  double fy = (1.0 - v) * e.h - 0.5;
+  int x0 = (int)std::floor(fx), y0 = (int)std::floor(fy);
+  int x1 = x0 + 1, y1 = y0 + 1;
+  double tx = fx - x0, ty = fy - y0;
+  x0 = ((x0 % e.w) + e.w) % e.w; x1 = ((x1 % e.w) + e.w) % e.w;
+  y0 = std::clamp(y0, 0, e.h - 1); y1 = std::clamp(y1, 0, e.h - 1);
+  auto px = [&](int x, int y) -> V3 {
+    size_t idx = ((size_t)y * e.w + x) * 3;
+    return {e.texel[idx] * e.intensity, e.texel[idx + 1] * e.intensity, e.texel[idx + 2] * e.intensity};
+  };
+  V3 c0 = lerp(px(x0, y0), px(x1, y0), tx);
+  V3 c1 = lerp(px(x0, y1), px(x1, y1), tx);
+  return lerp(c0, c1, ty);
+}
+
+double env_pdf(const EnvMap& e, V3 direction) {
+  if (!e.valid() || e.marginal.empty() || e.conditional.empty() || e.total <= 0.0) return 0.0;
+  V3 d = normalize(direction);
+  if (e.rotation != 0.0) {
+    double cr = std::cos(e.rotation), sr = std::sin(e.rotation);
+    double nx = d.x * cr - d.z * sr, nz = d.x * sr + d.z * cr;
+    d.x = nx; d.z = nz;
+  }
+  double phi = std::atan2(d.z, d.x);
+  double theta = std::acos(std::clamp(d.y, -1.0, 1.0));
+  double u = 0.5 + phi / (2.0 * kPi);
+  double v = theta / kPi;
+  int x = (int)(u * e.w), y = (int)(v * e.h);
+  x = std::clamp(x, 0, e.w - 1); y = std::clamp(y, 0, e.h - 1);
+  double mp = (e.marginal[y + 1] - e.marginal[y]) * e.h;
+  size_t off = (size_t)y * (e.w + 1);
+  double cp = (e.conditional[off + x + 1] - e.conditional[off + x]) * e.w;
+  double pdf_uv = mp * cp;
+  double st = std::sin(theta);
+  if (st < 1e-10) return 0.0;
+  return pdf_uv / (2.0 * kPi * kPi * st);
+}
+
+struct EnvPick { V3 dir, emission; double pdf; bool valid; };
+EnvPick env_sample_direction(const EnvMap& e, double u1, double u2) {  // texture.hpp:555-627
+  EnvPick out{}; out.valid = false;
+  if (!e.valid() || e.marginal.empty() || e.conditional.empty()) return out;
+  int y = (int)(std::upper_bound(e.marginal.begin(), e.marginal.end(), u1) - e.marginal.begin()) - 1;
+  y = std::clamp(y, 0, e.h - 1);
+  double mb = e.marginal[y], ma = e.marginal[y + 1];
+  double row_t = (ma > mb) ? (u1 - mb) / (ma - mb) : 0.0;
+  size_t off = (size_t)y * (e.w + 1);
+  auto cb = e.conditional.begin() + off;
+  int x = (int)(std::upper_bound(cb, cb + e.w + 1, u2) - cb) - 1;
+  x = std::clamp(x, 0, e.w - 1);
+  double lo = e.conditional[off + x], hi = e.conditional[off + x + 1];
+  double col_t = (hi > lo) ? (u2 - lo) / (hi - lo) : 0.0;
+  double u = (x + col_t + 0.5) / e.w;
+  double v = (y + row_t + 0.5) / e.h;
+  double phi = (u - 0.5) * 2.0 * kPi;
+  double theta = v * kPi;
+  double st = std::sin(theta), ct = std::cos(theta);
+  V3 dir = {st * std::cos(phi), ct, st * std::sin(phi)};
+  if (e.rotation != 0.0) {
+    double cr = std::cos(-e.rotation), sr = std::sin(-e.rotation);
+    double nx = dir.x * cr - dir.z * sr, nz = dir.x * sr + dir.z * cr;
+    dir.x = nx; dir.z = nz;
+  }
+  out.dir = dir;
+  out.emission = env_lookup(e, dir);
+  out.pdf = env_pdf(e, dir);
+  out.valid = out.pdf > 0.0;
+  return out;
+}
+
+// ----------------------------------------------------------------------------------------
+// materials / textures — material.hpp:71-76, :308-312; texture.hpp:268-310
+// ----------------------------------------------------------------------------------------
+V3 albedo_at(const orc_scene& s, const rtx_material& m, V3 p, double u, double v) {
+  if (!m.has_texture) return mk(m.albedo);
+  switch (m.tex_type) {
+    case RTX_TEX_SOLID: return mk(m.tex_color1);
+    case RTX_TEX_CHECKER: {
+      double inv = 1.0 / m.tex_scale;
+      int x = (int)std::floor(p.x * inv), y = (int)std::floor(p.y * inv), z = (int)std::floor(p.z * inv);
+      return ((x + y + z) % 2) == 0 ? mk(m.tex_color1) : mk(m.tex_color2);
+    }
+    case RTX_TEX_IMAGE: {
+      if (m.tex_image < 0 || m.tex_image >= (int)s.img_data.size()) return {1.0, 0.0, 1.0};
+      int w = s.img_w[m.tex_image], h = s.img_h[m.tex_image];
+      if (w == 0 || h == 0) return {1.0, 0.0, 1.0};
+      u = std::clamp(u, 0.0, 1.0);
+      v = 1.0 - std::clamp(v, 0.0, 1.0);
+      int i = (int)(u * w), j = (int)(v * h);
+      i = std::min(i, w - 1); j = std::min(j, h - 1);
+      const uint8_t* t = &s.img_data[m.tex_image][((size_t)j * w + i) * 3];
+      return {t[0] / 255.0, t[1] / 255.0, t[2] / 255.0};
+    }
+  }
+  return mk(m.tex_color1);
+}
+
+inline double schlick(double cosine, double ref_idx) {
+  double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+  r0 = r0 * r0;
+  return r0 + (1.0 - r0) * std::pow((1.0 - cosine), 5.0);
+}
+
+// ----------------------------------------------------------------------------------------
+// random numbers
+// ----------------------------------------------------------------------------------------
+inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
+  uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+  uint32_t n1 = (uint32_t)p1;
+  uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+  uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+  uint32_t k[2] = {key[0], key[1]};
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k);
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+inline double u24(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }
+
+// Sampler A: the reference's generator, drawn in the reference's order
+// (engine/renderer.cpp:33-56).  std::uniform_real_distribution is the same library type
+// the reference uses, so equal seeds give equal doubles.
+struct MtSampler {
+  std::mt19937 gen;
+  std::uniform_real_distribution<double> dist{0.0, 1.0};
+  double next() { return dist(gen); }
+  double range(double lo, double hi) { return lo + (hi - lo) * next(); }
+  void begin_sample(uint32_t, uint32_t, uint32_t) {}
+  void begin_bounce(int) {}
+  double jitter_x() { return next(); }
+  double jitter_y() { return next(); }
+  double light_select() { return next(); }
+  double light_u() { return next(); }
+  double light_v() { return next(); }
+  double fresnel() { return next(); }
+  double roulette() { return next(); }
+  V3 unit_vector() {  // random_in_unit_sphere + normalize, renderer.cpp:45-56
+    for (;;) {
+      double a = range(-1, 1), b = range(-1, 1), c = range(-1, 1);
+      V3 p = {a, b, c};
+      if (len2(p) < 1.0) return normalize(p);
+    }
+  }
+};
+
+// Sampler B: counter-based, identical to the GPU's.  key = (pixel index, seed);
+// counter = (sample index, block, 0, 0).  Block 0 holds the pixel jitter; bounce b uses
+// block 1+2b = {light select, light u, light v, roulette} and block 2+2b = {scatter u1,
+// scatter u2, fresnel, -}.  A uniform is the top 24 bits of a word times 2^-24, exactly
+// representable in float and double alike.
+struct CounterSampler {
+  uint32_t key[2]{0, 0}, sample = 0;
+  uint32_t a[4], b[4];
+  int bounce = -1;
+  bool have_a = false, have_b = false;
+  void block(uint32_t blk, uint32_t out[4]) { uint32_t c[4] = {sample, blk, 0, 0}; philox4x32_10(c, key, out); }
+  void begin_sample(uint32_t pixel, uint32_t seed, uint32_t s) { key[0] = pixel; key[1] = seed; sample = s; bounce = -1; have_a = false; }
+  void begin_bounce(int bn) { bounce = bn; have_a = have_b = false; }
+  uint32_t* A() { if (!have_a) { block(bounce < 0 ? 0u : 1u + 2u * (uint32_t)bounce, a); have_a = true; } return a; }
+  uint32_t* B() { if (!have_b) { block(2u + 2u * (uint32_t)bounce, b); have_b = true; } return b; }
+  double jitter_x() { return u24(A()[0]); }
+  double jitter_y() { return u24(A()[1]); }
+  double light_select() { return u24(A()[0]); }
+  double light_u() { return u24(A()[1]); }
+  double light_v() { return u24(A()[2]); }
+  double roulette() { return u24(A()[3]); }
+  double fresnel() { return u24(B()[2]); }
+  V3 unit_vector() {  // uniform on the sphere: same law as the normalised rejection sample
+    double z = 1.0 - 2.0 * u24(B()[0]);
+    double r = std::sqrt(std::fmax(0.0, 1.0 - z * z));
+    double phi = 2.0 * kPi * u24(B()[1]);
+    return {r * std::cos(phi), r * std::sin(phi), z};
+  }
+};
+
+// ----------------------------------------------------------------------------------------
+// light sampling — engine/scene.hpp:238-388 (sample), :407-463 (pdf), :470-488 (env pdf)
+// ----------------------------------------------------------------------------------------
+struct LightPick { V3 pos, n, Le; double pdf = 0, dist = 0; bool valid = false; };
+
+template <class S>
+LightPick sample_light(const orc_scene& s, V3 from, S& rng) {
+  LightPick out;
+  size_t np = s.points.size(), ne = s.emissive_spheres.size(), nq = s.quads.size(), nd = s.disks.size();
+  size_t total = np + ne + nq + nd;
+  bool has_env = s.has_env && s.env.importance();
+  if (total == 0 && !has_env) return out;
+  double rv = rng.light_select();
+  bool pick_env = false;
+  if (has_env && total > 0) {
+    pick_env = (rv < 0.5);
+    rv = pick_env ? (rv * 2.0) : ((rv - 0.5) * 2.0);
+  } else if (has_env) {
+    pick_env = true;
+  }
+  if (pick_env) {
+    double u1 = rng.light_u(), u2 = rng.light_v();
+    EnvPick e = env_sample_direction(s.env, u1, u2);
+    if (e.valid) {
+      out.pos = add(from, scale(e.dir, 1e6));
+      out.n = neg(e.dir);
+      out.Le = e.emission;
+      out.pdf = e.pdf;
+      out.dist = 1e6;
+      out.valid = true;
+      if (total > 0) out.pdf *= 0.5;
+    }
+    return out;
+  }
+  size_t idx = (size_t)(rv * total);
+  if (idx >= total) idx = total - 1;
+  size_t off = 0;
+  if (idx < np) {
+    const rtx_point_light& pl = s.points[idx];
+    out.pos = mk(pl.position); out.n = {0, -1, 0}; out.Le = mk(pl.intensity);
+    out.pdf = 1.0; out.dist = len(sub(out.pos, from)); out.valid = true;
+  }
+  off += np;
+  if (!out.valid && idx < off + ne) {  // sample_sphere_light, scene.hpp:238-273
+    const rtx_sphere& sp = s.spheres[s.emissive_spheres[idx - off]];
+    double z = 1.0 - 2.0 * rng.light_u();
+    double r = std::sqrt(std::fmax(0.0, 1.0 - z * z));
+    double phi = 2.0 * kPi * rng.light_v();
+    V3 local = {r * std::cos(phi), r * std::sin(phi), z};
+    out.pos = add(mk(sp.center), scale(local, sp.radius));
+    out.n = local;
+    out.Le = mk(s.mats[sp.material_id].emission);
+    double area = 4.0 * kPi * sp.radius * sp.radius;
+    out.pdf = 1.0 / area;
+    out.dist = len(sub(out.pos, from));
+    out.valid = true;
+  }
+  off += ne;
+  if (!out.valid && idx < off + nq) {
+    const rtx_quad_light& q = s.quads[idx - off];
+    double u = rng.light_u(), v = rng.light_v();
+    out.pos = add(mk(q.corner), add(scale(mk(q.edge_u), u), scale(mk(q.edge_v), v)));
+    out.n = mk(q.normal); out.Le = mk(q.emission);
+    out.pdf = 1.0 / q.area;
+    out.dist = len(sub(out.pos, from));
+    out.valid = true;
+  }
+  off += nq;
+  if (!out.valid && idx < off + nd) {  // DiskLight::sample_point, primitives.hpp:350-384
+    const rtx_disk_light& dl = s.disks[idx - off];
+    double u = rng.light_u(), v = rng.light_v();
+    double sx = 2.0 * u - 1.0, sy = 2.0 * v - 1.0;
+    V3 c = mk(dl.center);
+    if (sx == 0 && sy == 0) {
+      out.pos = c;
+    } else {
+      double rs, theta;
+      if (std::fabs(sx) > std::fabs(sy)) { rs = sx; theta = (kPi / 4.0) * (sy / sx); }
+      else { rs = sy; theta = (kPi / 2.0) - (kPi / 4.0) * (sx / sy); }
+      double ct = std::cos(theta), st = std::sin(theta);
+      double ar = dl.radius * rs;
+      V3 offv = add(scale(mk(dl.tangent), ar * ct), scale(mk(dl.bitangent), ar * st));
+      out.pos = add(c, offv);
+    }
+    out.n = mk(dl.normal); out.Le = mk(dl.emission);
+    out.pdf = 1.0 / dl.area;
+    out.dist = len(sub(out.pos, from));
+    out.valid = true;
+  }
+  if (out.valid) {
+    out.pdf /= (double)total;
+    if (has_env) out.pdf *= 0.5;
+  }
+  return out;
+}
+
+double light_pdf(const orc_scene& s, V3 lp) {
+  size_t total = s.points.size() + s.emissive_spheres.size() + s.quads.size() + s.disks.size();
+  bool has_env = s.has_env && s.env.importance();
+  if (total == 0 && !has_env) return 0.0;
+  double sel = 1.0 / (double)total;
+  if (has_env) sel *= 0.5;
+  for (int si : s.emissive_spheres) {
+    const rtx_sphere& sp = s.spheres[si];
+    double d2 = len2(sub(lp, mk(sp.center)));
+    double r2 = sp.radius * sp.radius;
+    if (std::abs(d2 - r2) < r2 * 0.01) { double area = 4.0 * kPi * r2; return sel / area; }
+  }
+  for (const rtx_quad_light& q : s.quads) {
+    V3 tp = sub(lp, mk(q.corner));
+    double dp = std::abs(dot(tp, mk(q.normal)));
+    if (dp < 0.01) {
+      double up = dot(tp, mk(q.edge_u)) / len2(mk(q.edge_u));
+      double vp = dot(tp, mk(q.edge_v)) / len2(mk(q.edge_v));
+      if (up >= -0.01 && up <= 1.01 && vp >= -0.01 && vp <= 1.01) return sel / q.area;
+    }
+  }
+  for (const rtx_disk_light& dl : s.disks) {
+    V3 tp = sub(lp, mk(dl.center));
+    double dp = std::abs(dot(tp, mk(dl.normal)));
+    double rad2 = len2(tp) - dp * dp;
+    if (dp < 0.01 && rad2 <= dl.radius * dl.radius * 1.01) return sel / dl.area;
+  }
+  return 0.0;
+}
+
+double env_light_pdf(const orc_scene& s, V3 dir) {
+  if (!s.has_env || !s.env.importance()) return 0.0;
+  size_t total = s.points.size() + s.emissive_spheres.size() + s.quads.size() + s.disks.size();
+  double pdf = env_pdf(s.env, dir);
+  if (total > 0) pdf *= 0.5;
+  return pdf;
+}
+
+V3 area_light_emission(const orc_scene& s, int id) {  // scene.hpp:686-700
+  if (id >= -(int)s.quads.size() && id < 0) return mk(s.quads[(size_t)(-id - 1)].emission);
+  if (id <= -1000) { size_t k = (size_t)(-id - 1000); if (k < s.disks.size()) return mk(s.disks[k].emission); }
+  return {0, 0, 0};
+}
+
+inline double power_heuristic(double a, double b) { double a2 = a * a, b2 = b * b; return a2 / (a2 + b2); }
+
+struct Tally { uint64_t closest = 0, shadow = 0, segments = 0; };
+
+V3 background(const orc_scene& s, const rtx_settings& st, const Ray& r) {  // renderer.cpp:978-994
+  if (s.has_env && s.env.valid()) return env_lookup(s.env, r.d);
+  if (st.use_background_gradient) {
+    V3 ud = normalize(r.d);
+    double t = 0.5 * (ud.y + 1.0);
+    return lerp(mk(st.background_bottom), mk(st.background_top), t);
+  }
+  return mk(st.background_color);
+}
+
+// Renderer::ray_color_path — engine/renderer.cpp:580-841, use_mnee = false.
+template <class S>
+V3 path_radiance(const orc_scene& s, const rtx_settings& st, Ray r, S& rng, Tally& tl) {
+  V3 thr = {1.0, 1.0, 1.0}, acc = {0.0, 0.0, 0.0};
+  Ray cur = r;
+  bool spec = false, was_diffuse = false;
+  double bsdf_pdf = 0.0;
+  const bool nee = st.use_nee != 0, mis = st.use_mis != 0;
+  const bool env_is = s.has_env && s.env.importance();
+  for (int bounce = 0; bounce < st.max_depth; ++bounce) {
+    rng.begin_bounce(bounce);
+    Hit rec;
+    tl.closest++;
+    if (!scene_hit(s, cur, 0.001, 1e9, rec)) {
+      V3 bg = background(s, st, cur);
+      bool handled = nee && mis && was_diffuse && env_is;
+      if (!handled) acc = add(acc, mul(thr, bg));
+      break;
+    }
+    tl.segments++;
+    if (rec.mat < 0) {  // area light, renderer.cpp:609-630
+      V3 Le = area_light_emission(s, rec.mat);
+      if (bounce == 0 || spec || !nee) {
+        acc = add(acc, mul(thr, Le));
+      } else if (mis && was_diffuse && bsdf_pdf > 0) {
+        double hd = rec.t;
+        double cl = std::abs(dot(rec.n, neg(normalize(cur.d))));
+        double lpa = light_pdf(s, rec.p);
+        if (lpa > 0 && cl > 0) {
+          double lps = lpa * hd * hd / cl;
+          double w = power_heuristic(bsdf_pdf, lps);
+          acc = add(acc, scale(mul(thr, Le), w));
+        }
+      }
+      break;
+    }
+    const rtx_material& m = s.mats[rec.mat];
+    V3 surf = albedo_at(s, m, rec.p, rec.u, rec.v);
+    if (bounce == 0 || spec || !nee) acc = add(acc, mul(thr, mk(m.emission)));
+    V3 sdir{0, 0, 0};
+    V3 atten = surf;
+    spec = false; was_diffuse = false; bsdf_pdf = 0.0;
+    switch (m.type) {
+      case RTX_MAT_LAMBERTIAN: {
+        if (nee) {
+          LightPick ls = sample_light(s, rec.p, rng);
+          if (ls.valid) {
+            bool is_env = ls.dist > 1e5;
+            V3 ldir; double ldist;
+            if (is_env) { ldir = normalize(sub(ls.pos, rec.p)); ldist = 1e9; }
+            else { V3 tl2 = sub(ls.pos, rec.p); ldist = len(tl2); ldir = scale(tl2, 1.0 / ldist); }
+            double cs = dot(rec.n, ldir);
+            if (cs > 0) {
+              Hit sh;
+              tl.shadow++;
+              bool occluded = scene_hit(s, Ray{rec.p, ldir}, 0.001, is_env ? 1e9 : (ldist - 0.001), sh);
+              if (!occluded) {
+                double lps; bool ok = true;
+                if (is_env) lps = ls.pdf;
+                else {
+                  double cl = std::abs(dot(ls.n, neg(ldir)));
+                  if (cl <= 0) ok = false;
+                  lps = ok ? ls.pdf * ldist * ldist / cl : 0.0;
+                }
+                if (ok && lps > 0) {
+                  double bpl = cs / kPi;
+                  double w = 1.0;
+                  if (mis) w = power_heuristic(lps, bpl);
+                  V3 direct = scale(mul(mul(ls.Le, surf), thr), cs / (kPi * lps) * w);
+                  acc = add(acc, direct);
+                }
+              }
+            }
+          }
+        }
+        sdir = add(rec.n, rng.unit_vector());
+        if (len2(sdir) < 1e-8) sdir = rec.n;
+        sdir = normalize(sdir);
+        bsdf_pdf = dot(rec.n, sdir) / kPi;
+        was_diffuse = true;
+        break;
+      }
+      case RTX_MAT_METAL: {
+        spec = true;
+        V3 refl = reflect(normalize(cur.d), rec.n);
+        if (m.fuzz > 0.0) { refl = add(refl, scale(rng.unit_vector(), m.fuzz)); spec = (m.fuzz < 0.1); }
+        sdir = refl;  // a direction below the surface is NOT terminated (renderer.cpp:755-758)
+        break;
+      }
+      case RTX_MAT_DIELECTRIC: {
+        spec = true;
+        atten = {1.0, 1.0, 1.0};
+        double ratio = rec.front ? (1.0 / m.refraction_index) : m.refraction_index;
+        V3 ud = normalize(cur.d);
+        double ct = std::fmin(dot(neg(ud), rec.n), 1.0);
+        double sn = std::sqrt(1.0 - ct * ct);
+        if (ratio * sn > 1.0 || schlick(ct, ratio) > rng.fresnel()) sdir = reflect(ud, rec.n);
+        else sdir = refract(ud, rec.n, ratio);
+        break;
+      }
+    }
+    thr = mul(thr, atten);
+    if (bounce > 3) {  // renderer.cpp:785-790
+      double p = std::fmax(thr.x, std::fmax(thr.y, thr.z));
+      if (p < 0.01) break;
+      if (rng.roulette() > p) break;
+      thr = scale(thr, 1.0 / p);
+    }
+    Ray next{rec.p, sdir};
+    if (nee && mis && !spec && bsdf_pdf > 0) {  // look-ahead, renderer.cpp:797-835
+      Hit nr;
+      tl.closest++;
+      if (scene_hit(s, next, 0.001, 1e9, nr)) {
+        // A negative id (quad/disk light) indexes before the material array in the reference
+        // (undefined behaviour); defined here as "not emissive": the arrival branch above
+        // already weights those hits.
+        if (nr.mat >= 0 && emissive(s.mats[nr.mat])) {
+          double hd = nr.t;
+          double cl = std::abs(dot(nr.n, neg(sdir)));
+          double lpa = light_pdf(s, nr.p);
+          if (lpa > 0 && cl > 0) {
+            double lps = lpa * hd * hd / cl;
+            double w = power_heuristic(bsdf_pdf, lps);
+            acc = add(acc, scale(mul(thr, mk(s.mats[nr.mat].emission)), w));
+          }
+        }
+      } else if (env_is) {
+        V3 ee = env_lookup(s.env, sdir);
+        double ep = env_light_pdf(s, sdir);
+        if (ep > 0) { double w = power_heuristic(bsdf_pdf, ep); acc = add(acc, scale(mul(thr, ee), w)); }
+      }
+    }
+    cur = next;
+  }
+  return acc;
+}
+
+inline Ray camera_ray(const rtx_camera& c, double s, double t) {  // scene.hpp:99-108
+  V3 o = mk(c.origin);
+  V3 d = sub(add(add(mk(c.lower_left_corner), scale(mk(c.horizontal), s)), scale(mk(c.vertical), t)), o);
+  return {o, d};
+}
+
+template <class S>
+void render_rows(const orc_scene& s, const rtx_camera& cam, const rtx_settings& st, S& rng, int y, double* film, Tally& tl) {
+  for (int x = 0; x < st.width; ++x) {
+    V3 px = {0, 0, 0};
+    for (int k = 0; k < st.samples_per_pixel; ++k) {
+      rng.begin_sample((uint32_t)(y * st.width + x), st.seed, (uint32_t)k);
+      double u = ((double)x + rng.jitter_x()) / st.width;
+      double v = ((double)y + rng.jitter_y()) / st.height;
+      Ray r = camera_ray(cam, u, v);
+      px = add(px, path_radiance(s, st, r, rng, tl));
+    }
+    px = scale(px, 1.0 / st.samples_per_pixel);
+    double* o = film + ((size_t)y * st.width + x) * 3;
+    o[0] = px.x; o[1] = px.y; o[2] = px.z;
+  }
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------
+extern "C" {
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
+
+int orc_create(const rtx_scene_desc* d, orc_scene** out) {
+  if (!d || !out) return RTX_ERR_INVALID_ARGUMENT;
+  orc_scene* s = new orc_scene();
+  s->spheres.assign(d->spheres, d->spheres + d->n_spheres);
+  s->planes.assign(d->planes, d->planes + d->n_planes);
+  s->tris.assign(d->triangles, d->triangles + d->n_triangles);
+  s->boxes.assign(d->boxes, d->boxes + d->n_boxes);
+  s->points.assign(d->point_lights, d->point_lights + d->n_point_lights);
+  s->quads.assign(d->quad_lights, d->quad_lights + d->n_quad_lights);
+  s->disks.assign(d->disk_lights, d->disk_lights + d->n_disk_lights);
+  s->mats.assign(d->materials, d->materials + d->n_materials);
+  for (size_t i = 0; i < d->n_images; ++i) {
+    const rtx_image& im = d->images[i];
+    s->img_data.emplace_back(im.rgb, im.rgb + (size_t)im.width * im.height * 3);
+    s->img_w.push_back(im.width); s->img_h.push_back(im.height);
+  }
+  if (d->environment && d->environment->rgb && d->environment->width > 0 && d->environment->height > 0) {
+    const rtx_environment& e = *d->environment;
+    s->env.texel.assign(e.rgb, e.rgb + (size_t)e.width * e.height * 3);
+    s->env.w = e.width; s->env.h = e.height; s->env.intensity = e.intensity; s->env.rotation = e.rotation;
+    build_env_cdf(s->env);
+    s->has_env = true;
+  }
+  for (size_t i = 0; i < s->spheres.size(); ++i) {
+    int m = s->spheres[i].material_id;
+    if (m >= 0 && m < (int)s->mats.size() && emissive(s->mats[m])) s->emissive_spheres.push_back((int)i);
+  }
+  build_bvh(*s);
+  *out = s;
+  return RTX_OK;
+}
+
+void orc_destroy(orc_scene* s) { delete s; }
+
+int orc_bvh_counts(const orc_scene* s, int64_t* n_nodes, int64_t* n_prims) {
+  *n_nodes = (int64_t)s->nodes.size(); *n_prims = (int64_t)s->prims.size();
+  return RTX_OK;
+}
+
+int orc_bvh_dump(const orc_scene* s, double* boxes6, int32_t* node_ints4, int32_t* prim_ints2) {
+  for (size_t i = 0; i < s->nodes.size(); ++i) {
+    const Node& n = s->nodes[i];
+    double b[6] = {n.box.lo.x, n.box.lo.y, n.box.lo.z, n.box.hi.x, n.box.hi.y, n.box.hi.z};
+    memcpy(boxes6 + i * 6, b, sizeof b);
+    node_ints4[i * 4] = n.left; node_ints4[i * 4 + 1] = n.right; node_ints4[i * 4 + 2] = n.first; node_ints4[i * 4 + 3] = n.count;
+  }
+  for (size_t i = 0; i < s->prims.size(); ++i) { prim_ints2[i * 2] = s->prims[i].type; prim_ints2[i * 2 + 1] = s->prims[i].index; }
+  return RTX_OK;
+}
+
+int orc_trace_closest(const orc_scene* s, const double* rays8, size_t n, rtx_hit* out, int threads) {
+  if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(static) num_threads(threads)
+  for (long long i = 0; i < (long long)n; ++i) {
+    const double* q = rays8 + (size_t)i * 8;
+    Ray r{{q[0], q[1], q[2]}, {q[3], q[4], q[5]}};
+    Hit h;
+    bool ok = scene_hit(*s, r, q[6], q[7], h);
+    rtx_hit& o = out[i];
+    memset(&o, 0, sizeof o);
+    o.hit = ok; o.prim_type = ok ? h.ptype : -1; o.prim_index = ok ? h.pidx : -1;
+    if (ok) {
+      o.material_id = h.mat; o.front_face = h.front; o.t = h.t;
+      o.point[0] = h.p.x; o.point[1] = h.p.y; o.point[2] = h.p.z;
+      o.normal[0] = h.n.x; o.normal[1] = h.n.y; o.normal[2] = h.n.z;
+      o.u = h.u; o.v = h.v;
+    }
+  }
+  return RTX_OK;
+}
+
+int orc_render(const orc_scene* s, const rtx_camera* cam, const rtx_settings* st, int rng_mode, int threads,
+               double* film, rtx_stats* stats) {
+  if (!s || !cam || !st || !film) return RTX_ERR_INVALID_ARGUMENT;
+  if (st->use_mnee) return RTX_ERR_UNSUPPORTED;
+  if (threads < 1) threads = 1;
+  const int W = st->width, H = st->height;
+  const int sc = st->shard_count > 0 ? st->shard_count : 1, si = st->shard_index;
+  memset(film, 0, sizeof(double) * (size_t)W * H * 3);
+  uint64_t closest = 0, shadow = 0, segments = 0, rows_done = 0;
+  double t0 = omp_get_wtime();
+  if (rng_mode == ORC_RNG_MT19937) {
+    // One generator per thread seeded seed + thread id, rows handed out in order; with one
+    // thread this is the reference's traversal order exactly.
+#pragma omp parallel num_threads(threads) reduction(+ : closest, shadow, segments, rows_done)
+    {
+      MtSampler rng;
+      rng.gen.seed(st->seed + (unsigned)omp_get_thread_num());
+      Tally tl;
+#pragma omp for schedule(dynamic, 1)
+      for (int y = 0; y < H; ++y) {
+        if (y % sc != si) continue;
+        render_rows(*s, *cam, *st, rng, y, film, tl);
+        rows_done++;
+      }
+      closest += tl.closest; shadow += tl.shadow; segments += tl.segments;
+    }
+  } else {
+#pragma omp parallel num_threads(threads) reduction(+ : closest, shadow, segments, rows_done)
+    {
+      CounterSampler rng;
+      Tally tl;
+#pragma omp for schedule(dynamic, 1)
+      for (int y = 0; y < H; ++y) {
+        if (y % sc != si) continue;
+        render_rows(*s, *cam, *st, rng, y, film, tl);
+        rows_done++;
+      }
+      closest += tl.closest; shadow += tl.shadow; segments += tl.segments;
+    }
+  }
+  if (stats) {
+    memset(stats, 0, sizeof *stats);
+    stats->samples = rows_done * (uint64_t)W * (uint64_t)st->samples_per_pixel;
+    stats->rays_closest = closest; stats->rays_shadow = shadow; stats->segments = segments;
+    stats->seconds_render = stats->seconds_total = omp_get_wtime() - t0;
+  }
+  return RTX_OK;
+}
+
+int orc_kat(const orc_scene* s, unsigned seed, int n, double* out, size_t cap, size_t* written) {
+  MtSampler rng;
+  rng.gen.seed(seed);
+  std::vector<double> o;
+  for (int i = 0; i < n; ++i) {
+    double px = rng.range(-3, 3), py = rng.range(0, 5), pz = rng.range(-5, 2);
+    V3 p = {px, py, pz};
+    LightPick ls = sample_light(*s, p, rng);
+    o.push_back(ls.valid ? 1.0 : 0.0);
+    if (ls.valid) {
+      double v[11] = {ls.pos.x, ls.pos.y, ls.pos.z, ls.n.x, ls.n.y, ls.n.z, ls.Le.x, ls.Le.y, ls.Le.z, ls.pdf, ls.dist};
+      o.insert(o.end(), v, v + 11);
+      o.push_back(light_pdf(*s, ls.pos));
+    }
+    double dx = rng.range(-1, 1), dy = rng.range(-1, 1), dz = rng.range(-1, 1);
+    V3 dir = {dx, dy, dz};
+    o.push_back(env_light_pdf(*s, dir));
+    if (s->has_env) { V3 c = env_lookup(s->env, dir); o.push_back(c.x); o.push_back(c.y); o.push_back(c.z); }
+    double uu = rng.next(), vv = rng.next();
+    for (const rtx_material& m : s->mats) { V3 a = albedo_at(*s, m, p, uu, vv); o.push_back(a.x); o.push_back(a.y); o.push_back(a.z); }
+    double cosv = rng.next(), ratio = (i & 1) ? 1.5 : 1.0 / 1.5;
+    o.push_back(schlick(cosv, ratio));
+    double nx = rng.range(-1, 1), ny = rng.range(-1, 1), nz = rng.range(-1, 1);
+    V3 nrm = normalize(V3{nx, ny, nz});
+    V3 ud = normalize(dir);
+    V3 rf = refract(ud, nrm, ratio), rl = reflect(ud, nrm);
+    double v6[6] = {rf.x, rf.y, rf.z, rl.x, rl.y, rl.z};
+    o.insert(o.end(), v6, v6 + 6);
+  }
+  *written = o.size();
+  if (o.size() > cap) return RTX_ERR_INVALID_ARGUMENT;
+  memcpy(out, o.data(), o.size() * 8);
+  return RTX_OK;
+}
+
+}  // extern "C"
