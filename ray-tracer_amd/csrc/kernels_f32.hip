@@ -1,0 +1,33 @@
+// Single-precision instantiations: the production kernels.
+#include "pt_kernels.hpp"
+#include "pt_host.hpp"
+
+namespace rtx {
+
+// Counterpart of the reference backend's smoke kernel (ref: engine/cuda/cuda_test.cu:14-19).
+__global__ void selftest_kernel(float* out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)i * 0.001f;
+}
+
+void launch_selftest(float* out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n);
+}
+
+void launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
+                         int grid, size_t lds_bytes, hipStream_t stream) {
+  hipLaunchKernelGGL(render_fused_kernel<float>, dim3(grid), dim3(kBlock), lds_bytes, stream, sc, cam, P, partial, counters);
+}
+
+void launch_film_reduce(const float* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream) {
+  unsigned grid = (unsigned)((npix * 3ull + 255) / 256);
+  hipLaunchKernelGGL(film_reduce_kernel<float>, dim3(grid), dim3(256), 0, stream, partial, film, npix, n_chunks, spp);
+}
+
+void launch_trace_fast(const DScene<float>& sc, const double* rays8, unsigned long long n, DHitOut* out, size_t lds_bytes, hipStream_t stream) {
+  if (n == 0) return;
+  unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(trace_fast_kernel<float>, dim3(grid), dim3(kBlock), lds_bytes, stream, sc, rays8, n, out);
+}
+
+}  // namespace rtx

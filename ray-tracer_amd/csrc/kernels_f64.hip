@@ -1,0 +1,79 @@
+// Double-precision instantiations: the parity / validation kernels.
+// Built with -ffp-contract=off so that no multiply-add is fused: the reference CPU build
+// (baseline x86-64) rounds after every multiply and every add, and so must these.
+#include "pt_kernels.hpp"
+#include "pt_host.hpp"
+
+namespace rtx {
+
+// Scene::hit (ref: engine/scene.hpp:574-674) on the reference-order binary BVH: same node
+// order (left before right; right pushed first), same 64-entry stack rules (:582-586,
+// :634-635), same acceptance of ties (a later primitive with equal t wins), same slab
+// test (engine/bvh.hpp:35-64).  One ray per lane; the per-lane stack lives in LDS.
+__global__ __launch_bounds__(64) void trace_ref_kernel(DScene<double> sc, DSceneRef ref, const double* __restrict__ rays8,
+                                                        unsigned long long n, DHitOut* __restrict__ out) {
+  __shared__ int stack_mem[64 * 64];
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int* stack = stack_mem + threadIdx.x;  // [level][lane]
+  const double* q = rays8 + i * 8ull;
+  Ray<double> r = {{q[0], q[1], q[2]}, {q[3], q[4], q[5]}};
+  const double t_min = q[6];
+  Cand<double> c;
+  cand_init(c, q[7]);
+  if (ref.n_nodes > 0) {
+    int sp = 0;
+    stack[(sp++) * 64] = 0;
+    while (sp > 0 && sp < 64) {
+      int ni = stack[(--sp) * 64];
+      if (ni < 0 || ni >= ref.n_nodes) continue;
+      const DNodeRef nd = ref.nodes[ni];
+      if (!slab_hit(nd.lo, nd.hi, r, t_min, c.t)) continue;
+      if (nd.count > 0) {
+        for (int k = 0; k < nd.count; ++k) {
+          int pi = nd.first + k;
+          if (pi < 0 || pi >= ref.n_prims) continue;
+          DPrimRef p = ref.prims[pi];
+          test_bounded(sc, p.type, p.index, r, t_min, c);
+        }
+      } else {
+        if (nd.right >= 0 && sp < 63) stack[(sp++) * 64] = nd.right;
+        if (nd.left >= 0 && sp < 63) stack[(sp++) * 64] = nd.left;
+      }
+    }
+  }
+  test_unbounded(sc, r, t_min, c);
+  DHitOut o;
+  const bool ok = c.type >= 0;
+  Hit<double> h;
+  h.p = {0, 0, 0}; h.n = {0, 0, 0}; h.t = 0; h.u = 0; h.v = 0; h.front = 0; h.mat = 0; h.type = -1; h.idx = -1;
+  if (ok) finalize_hit<double, true>(sc, r, c, h);
+  o.hit = ok; o.prim_type = h.type; o.prim_index = h.idx; o.material_id = h.mat; o.front_face = h.front; o.pad = 0;
+  o.t = h.t; o.point[0] = h.p.x; o.point[1] = h.p.y; o.point[2] = h.p.z;
+  o.normal[0] = h.n.x; o.normal[1] = h.n.y; o.normal[2] = h.n.z; o.u = h.u; o.v = h.v;
+  out[i] = o;
+}
+
+void launch_trace_ref(const DScene<double>& sc, const DSceneRef& ref, const double* rays8, unsigned long long n, DHitOut* out, hipStream_t stream) {
+  if (n == 0) return;
+  unsigned grid = (unsigned)((n + 63) / 64);
+  hipLaunchKernelGGL(trace_ref_kernel, dim3(grid), dim3(64), 0, stream, sc, ref, rays8, n, out);
+}
+
+void launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters,
+                         int grid, size_t lds_bytes, hipStream_t stream) {
+  hipLaunchKernelGGL(render_fused_kernel<double>, dim3(grid), dim3(kBlock), lds_bytes, stream, sc, cam, P, partial, counters);
+}
+
+void launch_film_reduce(const double* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream) {
+  unsigned grid = (unsigned)((npix * 3ull + 255) / 256);
+  hipLaunchKernelGGL(film_reduce_kernel<double>, dim3(grid), dim3(256), 0, stream, partial, film, npix, n_chunks, spp);
+}
+
+void launch_trace_fast(const DScene<double>& sc, const double* rays8, unsigned long long n, DHitOut* out, size_t lds_bytes, hipStream_t stream) {
+  if (n == 0) return;
+  unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(trace_fast_kernel<double>, dim3(grid), dim3(kBlock), lds_bytes, stream, sc, rays8, n, out);
+}
+
+}  // namespace rtx

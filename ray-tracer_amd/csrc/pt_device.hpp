@@ -1,0 +1,863 @@
+// gfx950 device code of the path tracer, templated on the arithmetic type R.
+//
+//   R = double : parity mode.  Expressions keep the reference's operand order and the
+//                translation unit is compiled with -ffp-contract=off, so closest hits are
+//                bit-identical to the CPU renderer.
+//   R = float  : production mode (contraction allowed).
+//
+// Reference lines are cited per routine; `ref:` paths are relative to the reference root.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "pt_types.hpp"
+
+namespace rtx {
+
+#define RTX_DEV __device__ __forceinline__
+
+template <class R> struct V3 { R x, y, z; };
+
+template <class R> RTX_DEV V3<R> mk3(const R* p) { return {p[0], p[1], p[2]}; }
+template <class R> RTX_DEV V3<R> operator+(V3<R> a, V3<R> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class R> RTX_DEV V3<R> operator-(V3<R> a, V3<R> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class R> RTX_DEV V3<R> operator*(V3<R> a, V3<R> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <class R> RTX_DEV V3<R> operator*(V3<R> a, R t) { return {a.x * t, a.y * t, a.z * t}; }
+template <class R> RTX_DEV V3<R> operator-(V3<R> a) { return {-a.x, -a.y, -a.z}; }
+// ref: core/vec3.c:37-63
+template <class R> RTX_DEV R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class R> RTX_DEV V3<R> cross(V3<R> a, V3<R> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <class R> RTX_DEV R len2(V3<R> v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+RTX_DEV float rsqrt_(float x) { return __frsqrt_rn(x); }
+RTX_DEV float sqrt_(float x) { return __fsqrt_rn(x); }
+RTX_DEV double sqrt_(double x) { return sqrt(x); }
+RTX_DEV float abs_(float x) { return fabsf(x); }
+RTX_DEV double abs_(double x) { return fabs(x); }
+RTX_DEV float min_(float a, float b) { return fminf(a, b); }
+RTX_DEV double min_(double a, double b) { return fmin(a, b); }
+RTX_DEV float max_(float a, float b) { return fmaxf(a, b); }
+RTX_DEV double max_(double a, double b) { return fmax(a, b); }
+template <class R> RTX_DEV R len(V3<R> v) { return sqrt_(len2(v)); }
+template <class R> RTX_DEV V3<R> normalize(V3<R> v) {
+  R l = len(v);
+  if (l > R(0)) return v * (R(1) / l);
+  return v;
+}
+// ref: core/vec3.c:65-83
+template <class R> RTX_DEV V3<R> reflect(V3<R> v, V3<R> n) { return v - n * (R(2) * dot(v, n)); }
+template <class R> RTX_DEV V3<R> refract(V3<R> uv, V3<R> n, R eta) {
+  R ct = min_(dot(-uv, n), R(1));
+  V3<R> perp = (uv + n * ct) * eta;
+  R par = -sqrt_(abs_(R(1) - len2(perp)));
+  return perp + n * par;
+}
+template <class R> RTX_DEV V3<R> lerp3(V3<R> a, V3<R> b, R t) { return a * (R(1) - t) + b * t; }
+
+template <class R> struct Consts;
+template <> struct Consts<float> { static constexpr float pi = 3.14159265358979323846f; };
+template <> struct Consts<double> { static constexpr double pi = 3.14159265358979323846; };
+
+RTX_DEV void sincos_(float x, float* s, float* c) { __sincosf(x, s, c); }
+RTX_DEV void sincos_(double x, double* s, double* c) { sincos(x, s, c); }
+// sin/cos of 2*pi*u for u in [0,1): the hardware sine takes its argument in revolutions.
+RTX_DEV void sincos_turns(float u, float* s, float* c) {
+  *s = __builtin_amdgcn_sinf(u);
+  *c = __builtin_amdgcn_cosf(u);
+}
+RTX_DEV void sincos_turns(double u, double* s, double* c) { sincos(2.0 * Consts<double>::pi * u, s, c); }
+
+template <class R> struct Ray { V3<R> o, d; };
+template <class R> RTX_DEV V3<R> at(const Ray<R>& r, R t) { return r.o + r.d * t; }  // ref: core/ray.c:12
+
+// The winner of a closest-hit query.  Point/normal are derived from it afterwards, once,
+// instead of after every successful primitive test.
+template <class R> struct Cand {
+  R t;
+  int type, idx;
+  // hit_record::u/v survive across primitive tests in the reference (scene.hpp:575,629): a
+  // plane or box hit reports the u,v of the last sphere/triangle/quad/disk test that
+  // succeeded before it.  uv_kind: 0 none (0,0), 1 values in (ua, ub), 2 sphere `uv_idx` at t = ua.
+  R ua, ub;
+  int uv_kind, uv_idx;
+};
+
+template <class R> struct Hit {
+  V3<R> p, n;
+  R t, u, v;
+  int front, mat, type, idx;
+};
+
+// ------------------------------------------------------------------------------------------
+// primitive tests: return acceptance and the accepted parameter only
+// ------------------------------------------------------------------------------------------
+
+// ref: engine/bvh.hpp:35-64 (AABB::hit).  The ternaries keep the old bound when the slab
+// value is NaN (0 * inf), exactly as the reference's do.
+template <class R> RTX_DEV bool slab_hit(const R* lo, const R* hi, const Ray<R>& r, R t_min, R t_max) {
+  R inv = R(1) / r.d.x;
+  R t0 = (lo[0] - r.o.x) * inv, t1 = (hi[0] - r.o.x) * inv;
+  if (inv < R(0)) { R s = t0; t0 = t1; t1 = s; }
+  t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
+  if (t_max <= t_min) return false;
+  inv = R(1) / r.d.y;
+  t0 = (lo[1] - r.o.y) * inv; t1 = (hi[1] - r.o.y) * inv;
+  if (inv < R(0)) { R s = t0; t0 = t1; t1 = s; }
+  t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
+  if (t_max <= t_min) return false;
+  inv = R(1) / r.d.z;
+  t0 = (lo[2] - r.o.z) * inv; t1 = (hi[2] - r.o.z) * inv;
+  if (inv < R(0)) { R s = t0; t0 = t1; t1 = s; }
+  t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
+  if (t_max <= t_min) return false;
+  return true;
+}
+
+// ref: engine/sphere.hpp:71-92
+template <class R> RTX_DEV bool sphere_t(const DSphere<R>& s, const Ray<R>& r, R t_min, R t_max, R& t_out) {
+  V3<R> oc = r.o - mk3(s.c);
+  R a = len2(r.d);
+  R half_b = dot(oc, r.d);
+  R c = len2(oc) - s.radius * s.radius;
+  R disc = half_b * half_b - a * c;
+  if (disc < R(0)) return false;
+  R sq = sqrt_(disc);
+  R root = (-half_b - sq) / a;
+  if (root < t_min || root > t_max) {
+    root = (-half_b + sq) / a;
+    if (root < t_min || root > t_max) return false;
+  }
+  t_out = root;
+  return true;
+}
+
+// ref: engine/primitives.hpp:35-48
+template <class R> RTX_DEV bool plane_t(const DPlane<R>& pl, const Ray<R>& r, R t_min, R t_max, R& t_out) {
+  V3<R> n = mk3(pl.n);
+  R denom = dot(n, r.d);
+  if (abs_(denom) < R(1e-8)) return false;
+  R t = dot(mk3(pl.p) - r.o, n) / denom;
+  if (t < t_min || t > t_max) return false;
+  t_out = t;
+  return true;
+}
+
+// ref: engine/primitives.hpp:78-110 (Moller-Trumbore, two-sided)
+template <class R> RTX_DEV bool tri_t(const DTri<R>& tr, const Ray<R>& r, R t_min, R t_max, R& t_out, R& u_out, R& v_out) {
+  V3<R> v0 = mk3(tr.v0);
+  V3<R> e1 = mk3(tr.v1) - v0, e2 = mk3(tr.v2) - v0;
+  V3<R> h = cross(r.d, e2);
+  R a = dot(e1, h);
+  if (abs_(a) < R(1e-8)) return false;
+  R f = R(1) / a;
+  V3<R> s = r.o - v0;
+  R u = f * dot(s, h);
+  if (u < R(0) || u > R(1)) return false;
+  V3<R> q = cross(s, e1);
+  R v = f * dot(r.d, q);
+  if (v < R(0) || u + v > R(1)) return false;
+  R t = f * dot(e2, q);
+  if (t < t_min || t > t_max) return false;
+  t_out = t; u_out = u; v_out = v;
+  return true;
+}
+
+// ref: engine/primitives.hpp:153-181.  The reported parameter is the slab entry, or the
+// caller's t_min when the origin is inside the box.
+template <class R> RTX_DEV bool box_t(const DBox<R>& b, const Ray<R>& r, R t_min, R t_max, R& t_out) {
+  R tmin = t_min, tmax = t_max;
+  const R o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    R inv = R(1) / d[ax];
+    R t0 = (b.lo[ax] - o[ax]) * inv, t1 = (b.hi[ax] - o[ax]) * inv;
+    if (inv < R(0)) { R s = t0; t0 = t1; t1 = s; }
+    tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
+    if (tmax <= tmin) return false;
+  }
+  t_out = tmin;
+  return true;
+}
+
+// ref: engine/primitives.hpp:274-300
+template <class R> RTX_DEV bool quad_t(const DQuad<R>& q, const Ray<R>& r, R t_min, R t_max, R& t_out, R& u_out, R& v_out) {
+  V3<R> n = mk3(q.n);
+  R denom = dot(n, r.d);
+  if (abs_(denom) < R(1e-8)) return false;
+  V3<R> corner = mk3(q.corner);
+  R t = dot(corner - r.o, n) / denom;
+  if (t < t_min || t > t_max) return false;
+  V3<R> d = at(r, t) - corner;
+  V3<R> eu = mk3(q.eu), ev = mk3(q.ev);
+  R up = dot(d, eu) / len2(eu), vp = dot(d, ev) / len2(ev);
+  if (up < R(0) || up > R(1) || vp < R(0) || vp > R(1)) return false;
+  t_out = t; u_out = up; v_out = vp;
+  return true;
+}
+
+// ref: engine/primitives.hpp:396-430
+template <class R> RTX_DEV bool disk_t(const DDisk<R>& dl, const Ray<R>& r, R t_min, R t_max, R& t_out, R& u_out, R& v_out) {
+  V3<R> n = mk3(dl.n);
+  R denom = dot(n, r.d);
+  if (abs_(denom) < R(1e-8)) return false;
+  V3<R> c = mk3(dl.c);
+  R t = dot(c - r.o, n) / denom;
+  if (t < t_min || t > t_max) return false;
+  V3<R> d = at(r, t) - c;
+  R d2 = len2(d);
+  if (d2 > dl.radius * dl.radius) return false;
+  R dist = sqrt_(d2);
+  u_out = (dist > R(1e-8)) ? (dot(d, mk3(dl.tan)) / dist + R(1)) * R(0.5) : R(0.5);
+  v_out = (dist > R(1e-8)) ? (dot(d, mk3(dl.bit)) / dist + R(1)) * R(0.5) : R(0.5);
+  t_out = t;
+  return true;
+}
+
+template <class R> RTX_DEV void cand_init(Cand<R>& c, R t_max) {
+  c.t = t_max; c.type = -1; c.idx = -1; c.ua = R(0); c.ub = R(0); c.uv_kind = 0; c.uv_idx = -1;
+}
+
+// One bounded primitive (sphere / triangle / box) against the current candidate.
+template <class R> RTX_DEV void test_bounded(const DScene<R>& sc, int type, int idx, const Ray<R>& r, R t_min, Cand<R>& c) {
+  R t, u, v;
+  if (type == PRIM_SPHERE) {
+    if (sphere_t(sc.spheres[idx], r, t_min, c.t, t)) { c.t = t; c.type = PRIM_SPHERE; c.idx = idx; c.uv_kind = 2; c.ua = t; c.uv_idx = idx; }
+  } else if (type == PRIM_TRIANGLE) {
+    if (tri_t(sc.tris[idx], r, t_min, c.t, t, u, v)) { c.t = t; c.type = PRIM_TRIANGLE; c.idx = idx; c.uv_kind = 1; c.ua = u; c.ub = v; }
+  } else if (type == PRIM_BOX) {
+    if (box_t(sc.boxes[idx], r, t_min, c.t, t)) { c.t = t; c.type = PRIM_BOX; c.idx = idx; }
+  }
+}
+
+// Planes, quad lights, disk lights: the linear tail of Scene::hit (ref: engine/scene.hpp:640-671).
+template <class R> RTX_DEV void test_unbounded(const DScene<R>& sc, const Ray<R>& r, R t_min, Cand<R>& c) {
+  R t, u, v;
+  for (int i = 0; i < sc.n_planes; ++i)
+    if (plane_t(sc.planes[i], r, t_min, c.t, t)) { c.t = t; c.type = PRIM_PLANE; c.idx = i; }
+  for (int i = 0; i < sc.n_quads; ++i)
+    if (quad_t(sc.quads[i], r, t_min, c.t, t, u, v)) { c.t = t; c.type = PRIM_QUAD; c.idx = i; c.uv_kind = 1; c.ua = u; c.ub = v; }
+  for (int i = 0; i < sc.n_disks; ++i)
+    if (disk_t(sc.disks[i], r, t_min, c.t, t, u, v)) { c.t = t; c.type = PRIM_DISK; c.idx = i; c.uv_kind = 1; c.ua = u; c.ub = v; }
+}
+
+template <class R> RTX_DEV void face_normal(Hit<R>& h, const Ray<R>& r, V3<R> outward) {  // ref: core/hit.c:21-24
+  h.front = dot(r.d, outward) < R(0);
+  h.n = h.front ? outward : -outward;
+}
+
+// ref: engine/sphere.hpp:26-32 (get_sphere_uv)
+template <class R> RTX_DEV void sphere_uv(V3<R> on, R& u, R& v) {
+  R theta = acos(-on.y);
+  R phi = atan2(-on.z, on.x) + Consts<R>::pi;
+  u = phi / (R(2) * Consts<R>::pi);
+  v = theta / Consts<R>::pi;
+}
+
+// Point, normal, face and material of the winner (the writes the reference's hit routines
+// make on success: sphere.hpp:94-98, primitives.hpp:50-53,112-116,180-195,302-305,419-422,
+// scene.hpp:657,669).  WANT_UV also resolves hit_record::u/v.
+template <class R, bool WANT_UV> RTX_DEV void finalize_hit(const DScene<R>& sc, const Ray<R>& r, const Cand<R>& c, Hit<R>& h) {
+  h.t = c.t; h.type = c.type; h.idx = c.idx;
+  h.p = at(r, c.t);
+  h.u = R(0); h.v = R(0);
+  switch (c.type) {
+    case PRIM_SPHERE: {
+      const DSphere<R>& s = sc.spheres[c.idx];
+      face_normal(h, r, (h.p - mk3(s.c)) * (R(1) / s.radius));
+      h.mat = s.mat;
+      break;
+    }
+    case PRIM_PLANE: {
+      const DPlane<R>& pl = sc.planes[c.idx];
+      face_normal(h, r, mk3(pl.n));
+      h.mat = pl.mat;
+      break;
+    }
+    case PRIM_TRIANGLE: {
+      const DTri<R>& tr = sc.tris[c.idx];
+      V3<R> v0 = mk3(tr.v0);
+      face_normal(h, r, normalize(cross(mk3(tr.v1) - v0, mk3(tr.v2) - v0)));
+      h.mat = tr.mat;
+      break;
+    }
+    case PRIM_BOX: {
+      const DBox<R>& b = sc.boxes[c.idx];
+      const R eps = R(1e-4);
+      V3<R> on;
+      if (abs_(h.p.x - b.lo[0]) < eps) on = {R(-1), R(0), R(0)};
+      else if (abs_(h.p.x - b.hi[0]) < eps) on = {R(1), R(0), R(0)};
+      else if (abs_(h.p.y - b.lo[1]) < eps) on = {R(0), R(-1), R(0)};
+      else if (abs_(h.p.y - b.hi[1]) < eps) on = {R(0), R(1), R(0)};
+      else if (abs_(h.p.z - b.lo[2]) < eps) on = {R(0), R(0), R(-1)};
+      else on = {R(0), R(0), R(1)};
+      face_normal(h, r, on);
+      h.mat = b.mat;
+      break;
+    }
+    case PRIM_QUAD: face_normal(h, r, mk3(sc.quads[c.idx].n)); h.mat = -c.idx - 1; break;
+    default: face_normal(h, r, mk3(sc.disks[c.idx].n)); h.mat = -1000 - c.idx; break;
+  }
+  if (WANT_UV) {
+    if (c.uv_kind == 1) { h.u = c.ua; h.v = c.ub; }
+    else if (c.uv_kind == 2) {
+      const DSphere<R>& s = sc.spheres[c.uv_idx];
+      V3<R> on = (at(r, c.ua) - mk3(s.c)) * (R(1) / s.radius);
+      sphere_uv(on, h.u, h.v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// closest hit / any hit through the production BVH
+// ------------------------------------------------------------------------------------------
+// Per-lane traversal stack in LDS, laid out [level][lane] so a wave's accesses to one level
+// are one conflict-free row.
+struct LaneStack {
+  int* base; int stride;
+  RTX_DEV int& at(int level) const { return base[level * stride]; }
+};
+
+template <class R> RTX_DEV R slab_entry(const DNode2<R>& nd, const Ray<R>& r, V3<R> inv, R t_min, R t_max, bool& ok) {
+  R t0 = (nd.lo[0] - r.o.x) * inv.x, t1 = (nd.hi[0] - r.o.x) * inv.x;
+  R lo = min_(t0, t1), hi = max_(t0, t1);
+  t0 = (nd.lo[1] - r.o.y) * inv.y; t1 = (nd.hi[1] - r.o.y) * inv.y;
+  lo = max_(lo, min_(t0, t1)); hi = min_(hi, max_(t0, t1));
+  t0 = (nd.lo[2] - r.o.z) * inv.z; t1 = (nd.hi[2] - r.o.z) * inv.z;
+  lo = max_(lo, min_(t0, t1)); hi = min_(hi, max_(t0, t1));
+  lo = max_(lo, t_min); hi = min_(hi, t_max);
+  ok = lo <= hi;
+  return lo;
+}
+
+template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, const Ray<R>& r, R t_min, Cand<R>& c, LaneStack st) {
+  if (sc.n_prims <= 0) return false;
+  if (sc.n_prims <= kLinearMaxPrims) {
+    for (int i = 0; i < sc.n_prims; ++i) {
+      DPrimRef p = sc.prims[i];
+      test_bounded(sc, p.type, p.index, r, t_min, c);
+      if (ANY && c.type >= 0) return true;
+    }
+    return c.type >= 0;
+  }
+  V3<R> inv = {R(1) / r.d.x, R(1) / r.d.y, R(1) / r.d.z};
+  int sp = 0;
+  int node = 0;
+  for (;;) {
+    const DNode2<R> nd = sc.nodes[node];
+    bool ok;
+    slab_entry(nd, r, inv, t_min, c.t, ok);
+    bool descend = false;
+    if (ok) {
+      if (nd.count > 0) {
+        for (int i = 0; i < nd.count; ++i) {
+          DPrimRef p = sc.prims[nd.a + i];
+          test_bounded(sc, p.type, p.index, r, t_min, c);
+        }
+        if (ANY && c.type >= 0) return true;
+      } else {
+        // visit the nearer child first; the other goes on the stack
+        bool ok_l, ok_r;
+        const DNode2<R> l = sc.nodes[node + 1];
+        const DNode2<R> rr = sc.nodes[nd.a];
+        R el = slab_entry(l, r, inv, t_min, c.t, ok_l);
+        R er = slab_entry(rr, r, inv, t_min, c.t, ok_r);
+        if (ok_l && ok_r) {
+          int near = el <= er ? node + 1 : nd.a, far = el <= er ? nd.a : node + 1;
+          if (sp < kStackDepth) st.at(sp++) = far;
+          node = near; descend = true;
+        } else if (ok_l) { node = node + 1; descend = true; }
+        else if (ok_r) { node = nd.a; descend = true; }
+      }
+    }
+    if (!descend) {
+      if (sp == 0) break;
+      node = st.at(--sp);
+    }
+  }
+  return c.type >= 0;
+}
+
+template <class R, bool WANT_UV> RTX_DEV bool closest_hit(const DScene<R>& sc, const Ray<R>& r, R t_min, R t_max, Hit<R>& h, LaneStack st) {
+  Cand<R> c;
+  cand_init(c, t_max);
+  walk_bounded<R, false>(sc, r, t_min, c, st);
+  test_unbounded(sc, r, t_min, c);
+  if (c.type < 0) return false;
+  finalize_hit<R, WANT_UV>(sc, r, c, h);
+  return true;
+}
+
+// Visibility: "does Scene::hit return true on [t_min, t_max]" (ref: engine/renderer.cpp:679).
+template <class R> RTX_DEV bool occluded(const DScene<R>& sc, const Ray<R>& r, R t_min, R t_max, LaneStack st) {
+  Cand<R> c;
+  cand_init(c, t_max);
+  if (walk_bounded<R, true>(sc, r, t_min, c, st)) return true;
+  R t, u, v;
+  bool any = false;
+  for (int i = 0; i < sc.n_planes; ++i) any |= plane_t(sc.planes[i], r, t_min, t_max, t);
+  for (int i = 0; i < sc.n_quads; ++i) any |= quad_t(sc.quads[i], r, t_min, t_max, t, u, v);
+  for (int i = 0; i < sc.n_disks; ++i) any |= disk_t(sc.disks[i], r, t_min, t_max, t, u, v);
+  return any;
+}
+
+// ------------------------------------------------------------------------------------------
+// counter-based random numbers: Philox-4x32-10, key = (pixel, seed), counter = (sample, block)
+// block 0: pixel jitter; bounce b: block 1+2b = {light select, light u, light v, roulette},
+// block 2+2b = {scatter u1, scatter u2, fresnel, -}.  A uniform is the top 24 bits of a word
+// times 2^-24: exactly representable in float and double, so both precisions see equal numbers.
+// ------------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+RTX_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1) {
+  uint32_t c2 = 0, c3 = 0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return {c0, c1, c2, c3};
+}
+template <class R> RTX_DEV R u24(uint32_t x) { return R(x >> 8) * R(1.0 / 16777216.0); }
+
+// Uniform direction on the unit sphere from two uniforms (same law as the reference's
+// normalised rejection sample, ref: engine/renderer.cpp:45-56).
+template <class R> RTX_DEV V3<R> unit_vector(R u1, R u2) {
+  R z = R(1) - R(2) * u1;
+  R rr = sqrt_(max_(R(0), R(1) - z * z));
+  R s, c;
+  sincos_turns(u2, &s, &c);
+  return {rr * c, rr * s, z};
+}
+
+// ------------------------------------------------------------------------------------------
+// environment map (ref: engine/texture.hpp:487-549 lookup, :555-627 sampling, :634-687 pdf)
+// ------------------------------------------------------------------------------------------
+template <class R> RTX_DEV V3<R> env_rotate(const DEnv<R>& e, V3<R> d, R sign) {
+  if (e.rotation != R(0)) {
+    R s, c;
+    sincos_(sign * e.rotation, &s, &c);
+    R nx = d.x * c - d.z * s, nz = d.x * s + d.z * c;
+    d.x = nx; d.z = nz;
+  }
+  return d;
+}
+RTX_DEV float floor_(float x) { return floorf(x); }
+RTX_DEV double floor_(double x) { return floor(x); }
+RTX_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+template <class R> RTX_DEV R clamp_(R v, R lo, R hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <class R> RTX_DEV V3<R> env_lookup(const DEnv<R>& e, V3<R> direction) {
+  if (!e.valid) return {R(0), R(0), R(0)};
+  V3<R> d = env_rotate(e, normalize(direction), R(1));
+  R phi = atan2(d.z, d.x);
+  R theta = asin(clamp_(d.y, R(-1), R(1)));
+  R u = R(0.5) + phi / (R(2) * Consts<R>::pi);
+  R v = R(0.5) + theta / Consts<R>::pi;
+  R fx = u * R(e.w) - R(0.5);
+  R fy = (R(1) - v) * R(e.h) - R(0.5);
+  int x0 = (int)floor_(fx), y0 = (int)floor_(fy);
+  int x1 = x0 + 1, y1 = y0 + 1;
+  R tx = fx - R(x0), ty = fy - R(y0);
+  x0 = ((x0 % e.w) + e.w) % e.w; x1 = ((x1 % e.w) + e.w) % e.w;
+  y0 = clampi(y0, 0, e.h - 1); y1 = clampi(y1, 0, e.h - 1);
+  auto px = [&](int x, int y) -> V3<R> {
+    const float* t = e.texel + ((size_t)y * e.w + x) * 3;
+    return {R(t[0]) * e.intensity, R(t[1]) * e.intensity, R(t[2]) * e.intensity};
+  };
+  V3<R> c0 = lerp3(px(x0, y0), px(x1, y0), tx);
+  V3<R> c1 = lerp3(px(x0, y1), px(x1, y1), tx);
+  return lerp3(c0, c1, ty);
+}
+
+template <class R> RTX_DEV R env_pdf(const DEnv<R>& e, V3<R> direction) {
+  if (!e.importance) return R(0);
+  V3<R> d = env_rotate(e, normalize(direction), R(1));
+  R phi = atan2(d.z, d.x);
+  R theta = acos(clamp_(d.y, R(-1), R(1)));
+  R u = R(0.5) + phi / (R(2) * Consts<R>::pi);
+  R v = theta / Consts<R>::pi;
+  int x = clampi((int)(u * R(e.w)), 0, e.w - 1);
+  int y = clampi((int)(v * R(e.h)), 0, e.h - 1);
+  R mp = (e.marginal[y + 1] - e.marginal[y]) * R(e.h);
+  size_t off = (size_t)y * (e.w + 1);
+  R cp = (e.conditional[off + x + 1] - e.conditional[off + x]) * R(e.w);
+  R st = sin(theta);
+  if (st < R(1e-10)) return R(0);
+  return mp * cp / (R(2) * Consts<R>::pi * Consts<R>::pi * st);
+}
+
+// index of the first element greater than x, minus one (std::upper_bound - 1), clamped
+template <class R> RTX_DEV int cdf_bin(const R* cdf, int n_plus_1, R x) {
+  int lo = 0, hi = n_plus_1;  // first index with cdf[i] > x
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (cdf[mid] > x) hi = mid; else lo = mid + 1;
+  }
+  return clampi(lo - 1, 0, n_plus_1 - 2);
+}
+
+template <class R> RTX_DEV bool env_sample(const DEnv<R>& e, R u1, R u2, V3<R>& dir, V3<R>& Le, R& pdf) {
+  if (!e.valid) return false;
+  int y = cdf_bin(e.marginal, e.h + 1, u1);
+  R mb = e.marginal[y], ma = e.marginal[y + 1];
+  R row_t = (ma > mb) ? (u1 - mb) / (ma - mb) : R(0);
+  const R* cond = e.conditional + (size_t)y * (e.w + 1);
+  int x = cdf_bin(cond, e.w + 1, u2);
+  R lo = cond[x], hi = cond[x + 1];
+  R col_t = (hi > lo) ? (u2 - lo) / (hi - lo) : R(0);
+  R u = (R(x) + col_t + R(0.5)) / R(e.w);   // half-texel shift relative to env_pdf's binning, as in the reference
+  R v = (R(y) + row_t + R(0.5)) / R(e.h);
+  R phi = (u - R(0.5)) * R(2) * Consts<R>::pi;
+  R theta = v * Consts<R>::pi;
+  R st, ct, sp, cp;
+  sincos_(theta, &st, &ct);
+  sincos_(phi, &sp, &cp);
+  V3<R> d = {st * cp, ct, st * sp};
+  d = env_rotate(e, d, R(-1));
+  dir = d;
+  Le = env_lookup(e, d);
+  pdf = env_pdf(e, d);
+  return pdf > R(0);
+}
+
+// ------------------------------------------------------------------------------------------
+// materials (ref: engine/material.hpp:71-76, :115-117, :308-312; engine/texture.hpp:268-310)
+// ------------------------------------------------------------------------------------------
+template <class R> RTX_DEV bool is_emissive(const DMaterial<R>& m) {
+  return m.emission[0] > R(0) || m.emission[1] > R(0) || m.emission[2] > R(0);
+}
+
+template <class R> RTX_DEV V3<R> albedo_at(const DScene<R>& sc, const DMaterial<R>& m, const Hit<R>& h) {
+  if (!m.has_texture) return mk3(m.albedo);
+  if (m.tex_type == TEX_CHECKER) {
+    R inv = R(1) / m.scale;
+    int x = (int)floor_(h.p.x * inv), y = (int)floor_(h.p.y * inv), z = (int)floor_(h.p.z * inv);
+    return ((x + y + z) % 2) == 0 ? mk3(m.c1) : mk3(m.c2);
+  }
+  if (m.tex_type == TEX_IMAGE) {
+    if (m.tex_image < 0 || m.tex_image >= sc.n_images) return {R(1), R(0), R(1)};
+    DImage im = sc.images[m.tex_image];
+    if (im.w == 0 || im.h == 0) return {R(1), R(0), R(1)};
+    R u = clamp_(h.u, R(0), R(1));
+    R v = R(1) - clamp_(h.v, R(0), R(1));
+    int i = (int)(u * R(im.w)), j = (int)(v * R(im.h));
+    i = i < im.w - 1 ? i : im.w - 1; j = j < im.h - 1 ? j : im.h - 1;
+    const uint8_t* t = im.rgb + ((size_t)j * im.w + i) * 3;
+    return {R(t[0]) / R(255), R(t[1]) / R(255), R(t[2]) / R(255)};
+  }
+  return mk3(m.c1);
+}
+
+template <class R> RTX_DEV R schlick(R cosine, R ref_idx) {
+  R r0 = (R(1) - ref_idx) / (R(1) + ref_idx);
+  r0 = r0 * r0;
+  R x = R(1) - cosine;
+  R x2 = x * x;
+  return r0 + (R(1) - r0) * (x2 * x2 * x);
+}
+
+template <class R> RTX_DEV R power_heuristic(R a, R b) { R a2 = a * a, b2 = b * b; return a2 / (a2 + b2); }  // ref: engine/renderer.cpp:574-578
+
+// ------------------------------------------------------------------------------------------
+// light sampling (ref: engine/scene.hpp:238-388, :407-463, :470-488, :686-700)
+// ------------------------------------------------------------------------------------------
+template <class R> struct LightPick { V3<R> pos, n, Le; R pdf, dist; bool valid; };
+
+template <class R> RTX_DEV LightPick<R> sample_light(const DScene<R>& sc, V3<R> from, R rv, R lu, R lv) {
+  LightPick<R> out;
+  out.valid = false; out.pdf = R(0); out.dist = R(0);
+  out.pos = out.n = out.Le = {R(0), R(0), R(0)};
+  const int np = sc.n_points, ne = sc.n_emissive, nq = sc.n_quads, nd = sc.n_disks;
+  const int total = np + ne + nq + nd;
+  const bool has_env = sc.env.importance != 0;
+  if (total == 0 && !has_env) return out;
+  bool pick_env = false;
+  if (has_env && total > 0) {
+    pick_env = rv < R(0.5);
+    rv = pick_env ? (rv * R(2)) : ((rv - R(0.5)) * R(2));
+  } else if (has_env) {
+    pick_env = true;
+  }
+  if (pick_env) {
+    V3<R> d, Le; R pdf;
+    if (env_sample(sc.env, lu, lv, d, Le, pdf)) {
+      out.pos = from + d * R(1e6);
+      out.n = -d; out.Le = Le; out.pdf = pdf; out.dist = R(1e6); out.valid = true;
+      if (total > 0) out.pdf *= R(0.5);
+    }
+    return out;
+  }
+  int idx = (int)(rv * R(total));
+  if (idx >= total) idx = total - 1;
+  if (idx < np) {
+    const DPoint<R>& pl = sc.points[idx];
+    out.pos = mk3(pl.pos); out.n = {R(0), R(-1), R(0)}; out.Le = mk3(pl.I);
+    out.pdf = R(1);
+  } else if (idx < np + ne) {
+    const DSphere<R>& sp = sc.spheres[sc.emissive[idx - np]];
+    V3<R> local = unit_vector(lu, lv);  // z = 1-2u, phi = 2 pi v: scene.hpp:254-258
+    out.pos = mk3(sp.c) + local * sp.radius;
+    out.n = local;
+    out.Le = mk3(sc.mats[sp.mat].emission);
+    R area = R(4) * Consts<R>::pi * sp.radius * sp.radius;
+    out.pdf = R(1) / area;
+  } else if (idx < np + ne + nq) {
+    const DQuad<R>& q = sc.quads[idx - np - ne];
+    out.pos = mk3(q.corner) + (mk3(q.eu) * lu + mk3(q.ev) * lv);
+    out.n = mk3(q.n); out.Le = mk3(q.Le);
+    out.pdf = R(1) / q.area;
+  } else {
+    const DDisk<R>& dl = sc.disks[idx - np - ne - nq];   // ref: engine/primitives.hpp:350-384
+    R sx = R(2) * lu - R(1), sy = R(2) * lv - R(1);
+    V3<R> c = mk3(dl.c);
+    if (sx == R(0) && sy == R(0)) {
+      out.pos = c;
+    } else {
+      R rs, theta;
+      if (abs_(sx) > abs_(sy)) { rs = sx; theta = (Consts<R>::pi / R(4)) * (sy / sx); }
+      else { rs = sy; theta = (Consts<R>::pi / R(2)) - (Consts<R>::pi / R(4)) * (sx / sy); }
+      R st, ct;
+      sincos_(theta, &st, &ct);
+      R ar = dl.radius * rs;
+      out.pos = c + (mk3(dl.tan) * (ar * ct) + mk3(dl.bit) * (ar * st));
+    }
+    out.n = mk3(dl.n); out.Le = mk3(dl.Le);
+    out.pdf = R(1) / dl.area;
+  }
+  out.dist = len(out.pos - from);
+  out.valid = true;
+  out.pdf /= R(total);
+  if (has_env) out.pdf *= R(0.5);
+  return out;
+}
+
+template <class R> RTX_DEV R light_pdf(const DScene<R>& sc, V3<R> lp) {
+  const int total = sc.n_points + sc.n_emissive + sc.n_quads + sc.n_disks;
+  const bool has_env = sc.env.importance != 0;
+  if (total == 0 && !has_env) return R(0);
+  R sel = R(1) / R(total);
+  if (has_env) sel *= R(0.5);
+  for (int i = 0; i < sc.n_emissive; ++i) {
+    const DSphere<R>& sp = sc.spheres[sc.emissive[i]];
+    R d2 = len2(lp - mk3(sp.c));
+    R r2 = sp.radius * sp.radius;
+    if (abs_(d2 - r2) < r2 * R(0.01)) { R area = R(4) * Consts<R>::pi * r2; return sel / area; }
+  }
+  for (int i = 0; i < sc.n_quads; ++i) {
+    const DQuad<R>& q = sc.quads[i];
+    V3<R> tp = lp - mk3(q.corner);
+    R dp = abs_(dot(tp, mk3(q.n)));
+    if (dp < R(0.01)) {
+      R up = dot(tp, mk3(q.eu)) / len2(mk3(q.eu));
+      R vp = dot(tp, mk3(q.ev)) / len2(mk3(q.ev));
+      if (up >= R(-0.01) && up <= R(1.01) && vp >= R(-0.01) && vp <= R(1.01)) return sel / q.area;
+    }
+  }
+  for (int i = 0; i < sc.n_disks; ++i) {
+    const DDisk<R>& dl = sc.disks[i];
+    V3<R> tp = lp - mk3(dl.c);
+    R dp = abs_(dot(tp, mk3(dl.n)));
+    R rad2 = len2(tp) - dp * dp;
+    if (dp < R(0.01) && rad2 <= dl.radius * dl.radius * R(1.01)) return sel / dl.area;
+  }
+  return R(0);
+}
+
+template <class R> RTX_DEV R env_light_pdf(const DScene<R>& sc, V3<R> dir) {
+  if (!sc.env.importance) return R(0);
+  R pdf = env_pdf(sc.env, dir);
+  if (sc.n_points + sc.n_emissive + sc.n_quads + sc.n_disks > 0) pdf *= R(0.5);
+  return pdf;
+}
+
+template <class R> RTX_DEV V3<R> area_light_emission(const DScene<R>& sc, int id) {
+  if (id >= -sc.n_quads && id < 0) return mk3(sc.quads[-id - 1].Le);
+  if (id <= -1000) { int k = -id - 1000; if (k < sc.n_disks) return mk3(sc.disks[k].Le); }
+  return {R(0), R(0), R(0)};
+}
+
+template <class R> RTX_DEV V3<R> background(const DScene<R>& sc, const DRenderParams& P, const Ray<R>& r) {  // ref: engine/renderer.cpp:978-994
+  if (sc.env.valid) return env_lookup(sc.env, r.d);
+  if (P.use_gradient) {
+    V3<R> ud = normalize(r.d);
+    R t = R(0.5) * (ud.y + R(1));
+    V3<R> bot = {R(P.bg_bottom[0]), R(P.bg_bottom[1]), R(P.bg_bottom[2])};
+    V3<R> top = {R(P.bg_top[0]), R(P.bg_top[1]), R(P.bg_top[2])};
+    return lerp3(bot, top, t);
+  }
+  return {R(P.bg[0]), R(P.bg[1]), R(P.bg[2])};
+}
+
+// ------------------------------------------------------------------------------------------
+// the integrator, one path vertex at a time
+// ------------------------------------------------------------------------------------------
+// Renderer::ray_color_path (ref: engine/renderer.cpp:580-841, use_mnee = false) issues three
+// Scene::hit calls per diffuse bounce: the bounce's own closest hit, the shadow ray, and a
+// "look-ahead" closest hit of the ray the NEXT iteration traces again (:797-835).  Here the
+// look-ahead and the next iteration share one trace: `pending` marks that the vertex about to
+// be found still owes the previous vertex its MIS-weighted emission.
+template <class R> struct PathState {
+  Ray<R> ray;
+  V3<R> thr, acc;
+  R bsdf_pdf;
+  int bounce;
+  bool spec, was_diffuse, pending, alive;
+};
+
+struct PathKey { uint32_t pixel, seed, sample; };
+
+template <class R> RTX_DEV void path_begin(PathState<R>& ps, const DCamera<R>& cam, const DRenderParams& P, int x, int y, PathKey key) {
+  U4 j = philox4x32_10(key.sample, 0u, key.pixel, key.seed);
+  R u = (R(x) + u24<R>(j.x)) / R(P.width);     // ref: engine/renderer.cpp:385-386
+  R v = (R(y) + u24<R>(j.y)) / R(P.height);
+  V3<R> o = mk3(cam.origin);                    // ref: engine/scene.hpp:99-108
+  ps.ray.o = o;
+  ps.ray.d = ((mk3(cam.llc) + mk3(cam.horizontal) * u) + mk3(cam.vertical) * v) - o;
+  ps.thr = {R(1), R(1), R(1)};
+  ps.acc = {R(0), R(0), R(0)};
+  ps.bsdf_pdf = R(0);
+  ps.bounce = 0;
+  ps.spec = false; ps.was_diffuse = false; ps.pending = false; ps.alive = true;
+}
+
+struct StepCounts { uint32_t closest, shadow, segments; };
+
+// Advance one vertex: trace ps.ray, settle the previous vertex's pending MIS term, shade.
+template <class R> RTX_DEV void path_step(PathState<R>& ps, const DScene<R>& sc, const DRenderParams& P, PathKey key, LaneStack st, StepCounts& cnt) {
+  const bool nee = P.use_nee != 0, mis = P.use_mis != 0;
+  const bool env_is = sc.env.importance != 0;
+  const bool want_uv = sc.n_images > 0;
+  Hit<R> rec;
+  cnt.closest++;
+  bool hit = want_uv ? closest_hit<R, true>(sc, ps.ray, R(0.001), R(1e9), rec, st)
+                     : closest_hit<R, false>(sc, ps.ray, R(0.001), R(1e9), rec, st);
+
+  if (ps.pending) {  // ref: engine/renderer.cpp:797-835, evaluated on the shared trace
+    if (hit) {
+      // A quad/disk light id is negative; the reference indexes its material array with it
+      // (undefined behaviour).  Defined here as "not emissive": the arrival branch weights it.
+      if (rec.mat >= 0) {
+        const DMaterial<R>& nm = sc.mats[rec.mat];
+        if (is_emissive(nm)) {
+          R cl = abs_(dot(rec.n, -ps.ray.d));
+          R lpa = light_pdf(sc, rec.p);
+          if (lpa > R(0) && cl > R(0)) {
+            R lps = lpa * rec.t * rec.t / cl;
+            R w = power_heuristic(ps.bsdf_pdf, lps);
+            ps.acc = ps.acc + (ps.thr * mk3(nm.emission)) * w;
+          }
+        }
+      }
+    } else if (env_is) {
+      V3<R> ee = env_lookup(sc.env, ps.ray.d);
+      R ep = env_light_pdf(sc, ps.ray.d);
+      if (ep > R(0)) { R w = power_heuristic(ps.bsdf_pdf, ep); ps.acc = ps.acc + (ps.thr * ee) * w; }
+    }
+    ps.pending = false;
+  }
+  if (ps.bounce >= P.max_depth) { ps.alive = false; return; }
+
+  const int bounce = ps.bounce;
+  if (!hit) {  // ref: engine/renderer.cpp:591-606
+    bool handled = nee && mis && ps.was_diffuse && env_is;
+    if (!handled) ps.acc = ps.acc + ps.thr * background(sc, P, ps.ray);
+    ps.alive = false;
+    return;
+  }
+  cnt.segments++;
+  if (rec.mat < 0) {  // area light, ref: engine/renderer.cpp:609-630
+    V3<R> Le = area_light_emission(sc, rec.mat);
+    if (bounce == 0 || ps.spec || !nee) {
+      ps.acc = ps.acc + ps.thr * Le;
+    } else if (mis && ps.was_diffuse && ps.bsdf_pdf > R(0)) {
+      R cl = abs_(dot(rec.n, -normalize(ps.ray.d)));
+      R lpa = light_pdf(sc, rec.p);
+      if (lpa > R(0) && cl > R(0)) {
+        R lps = lpa * rec.t * rec.t / cl;
+        R w = power_heuristic(ps.bsdf_pdf, lps);
+        ps.acc = ps.acc + (ps.thr * Le) * w;
+      }
+    }
+    ps.alive = false;
+    return;
+  }
+  const DMaterial<R>& m = sc.mats[rec.mat];
+  V3<R> surf = albedo_at(sc, m, rec);
+  if (bounce == 0 || ps.spec || !nee) ps.acc = ps.acc + ps.thr * mk3(m.emission);
+
+  V3<R> sdir = {R(0), R(0), R(0)};
+  V3<R> atten = surf;
+  ps.spec = false; ps.was_diffuse = false; ps.bsdf_pdf = R(0);
+  const uint32_t blk = 1u + 2u * (uint32_t)bounce;
+  U4 ra = {0, 0, 0, 0};
+  const bool lamb = m.type == MAT_LAMBERTIAN;
+  if ((lamb && nee) || bounce > 3) ra = philox4x32_10(key.sample, blk, key.pixel, key.seed);
+  U4 rb = philox4x32_10(key.sample, blk + 1u, key.pixel, key.seed);
+
+  if (lamb) {
+    if (nee) {  // ref: engine/renderer.cpp:654-714
+      LightPick<R> ls = sample_light(sc, rec.p, u24<R>(ra.x), u24<R>(ra.y), u24<R>(ra.z));
+      if (ls.valid) {
+        bool is_env = ls.dist > R(1e5);
+        V3<R> ldir; R ldist;
+        if (is_env) { ldir = normalize(ls.pos - rec.p); ldist = R(1e9); }
+        else { V3<R> tl = ls.pos - rec.p; ldist = len(tl); ldir = tl * (R(1) / ldist); }
+        R cs = dot(rec.n, ldir);
+        if (cs > R(0)) {
+          cnt.shadow++;
+          Ray<R> sr = {rec.p, ldir};
+          bool occ = occluded(sc, sr, R(0.001), is_env ? R(1e9) : (ldist - R(0.001)), st);
+          if (!occ) {
+            R lps; bool ok = true;
+            if (is_env) lps = ls.pdf;
+            else {
+              R cl = abs_(dot(ls.n, -ldir));
+              ok = cl > R(0);
+              lps = ok ? ls.pdf * ldist * ldist / cl : R(0);
+            }
+            if (ok && lps > R(0)) {
+              R bpl = cs / Consts<R>::pi;
+              R w = mis ? power_heuristic(lps, bpl) : R(1);
+              ps.acc = ps.acc + ((ls.Le * surf) * ps.thr) * (cs / (Consts<R>::pi * lps) * w);
+            }
+          }
+        }
+      }
+    }
+    sdir = rec.n + unit_vector(u24<R>(rb.x), u24<R>(rb.y));   // ref: engine/renderer.cpp:737-743
+    if (len2(sdir) < R(1e-8)) sdir = rec.n;
+    sdir = normalize(sdir);
+    ps.bsdf_pdf = dot(rec.n, sdir) / Consts<R>::pi;
+    ps.was_diffuse = true;
+  } else if (m.type == MAT_METAL) {  // ref: engine/renderer.cpp:747-759 (below-surface directions continue)
+    ps.spec = true;
+    V3<R> refl = reflect(normalize(ps.ray.d), rec.n);
+    if (m.fuzz > R(0)) { refl = refl + unit_vector(u24<R>(rb.x), u24<R>(rb.y)) * m.fuzz; ps.spec = m.fuzz < R(0.1); }
+    sdir = refl;
+  } else {  // dielectric, ref: engine/renderer.cpp:761-778
+    ps.spec = true;
+    atten = {R(1), R(1), R(1)};
+    R ratio = rec.front ? (R(1) / m.ior) : m.ior;
+    V3<R> ud = normalize(ps.ray.d);
+    R ct = min_(dot(-ud, rec.n), R(1));
+    R sn = sqrt_(R(1) - ct * ct);
+    if (ratio * sn > R(1) || schlick(ct, ratio) > u24<R>(rb.z)) sdir = reflect(ud, rec.n);
+    else sdir = refract(ud, rec.n, ratio);
+  }
+  ps.thr = ps.thr * atten;
+  if (bounce > 3) {  // ref: engine/renderer.cpp:785-790
+    R p = max_(ps.thr.x, max_(ps.thr.y, ps.thr.z));
+    if (p < R(0.01) || u24<R>(ra.w) > p) { ps.alive = false; return; }
+    ps.thr = ps.thr * (R(1) / p);
+  }
+  ps.ray.o = rec.p;
+  ps.ray.d = sdir;
+  ps.pending = nee && mis && !ps.spec && ps.bsdf_pdf > R(0);
+  ps.bounce = bounce + 1;
+  if (ps.bounce >= P.max_depth && !ps.pending) ps.alive = false;
+}
+
+}  // namespace rtx

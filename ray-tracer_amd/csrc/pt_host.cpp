@@ -1,0 +1,301 @@
+// Scene upload: host BVH construction, float/double device copies, environment tables.
+#include "pt_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <type_traits>
+
+namespace rtx {
+
+// ------------------------------------------------------------------------------------------
+bool DeviceBuffer::ensure(size_t bytes) {
+  if (bytes <= cap && ptr) return true;
+  if (ptr) { hipFree(ptr); ptr = nullptr; cap = 0; }
+  if (bytes == 0) bytes = 16;
+  if (hipMalloc(&ptr, bytes) != hipSuccess) { ptr = nullptr; return false; }
+  cap = bytes;
+  return true;
+}
+bool DeviceBuffer::upload(const void* src, size_t bytes) {
+  if (!ensure(bytes)) return false;
+  if (bytes == 0) return true;
+  return hipMemcpy(ptr, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+}
+void DeviceBuffer::release() {
+  if (ptr) hipFree(ptr);
+  ptr = nullptr; cap = 0;
+}
+void WavefrontPool::release() { state.release(); queues.release(); control.release(); }
+
+// ------------------------------------------------------------------------------------------
+// Reference-order BVH.  Median split on the longest centroid axis with std::nth_element,
+// leaves of at most two primitives, nodes stored in preorder (ref: engine/bvh.hpp:148-218).
+// The number of nodes under a range depends only on its length, so every subtree's slot in
+// the preorder array is known up front and large subtrees can be built concurrently without
+// changing a single node.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct BuildPrim { double lo[3], hi[3]; int32_t index, type; };
+
+inline double cen(const BuildPrim& p, int ax) { return (p.lo[ax] + p.hi[ax]) * 0.5; }  // ref: bvh.hpp:89-95
+
+size_t subtree_nodes(size_t count) {
+  if (count <= 2) return 1;
+  size_t l = count / 2;
+  return 1 + subtree_nodes(l) + subtree_nodes(count - l);
+}
+
+struct Builder {
+  std::vector<BuildPrim>& prims;
+  std::vector<DNodeRef>& nodes;
+
+  void build(size_t me, size_t start, size_t end, int depth) {
+    DNodeRef& nd = nodes[me];
+    double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};   // ref: bvh.hpp:26-27
+    for (size_t i = start; i < end; ++i)
+      for (int a = 0; a < 3; ++a) {
+        // AABB::expand(other): expand(min) then expand(max), each an fmin + an fmax (bvh.hpp:69-84)
+        lo[a] = std::fmin(std::fmin(lo[a], prims[i].lo[a]), prims[i].hi[a]);
+        hi[a] = std::fmax(std::fmax(hi[a], prims[i].lo[a]), prims[i].hi[a]);
+      }
+    for (int a = 0; a < 3; ++a) { nd.lo[a] = lo[a]; nd.hi[a] = hi[a]; }
+    size_t count = end - start;
+    if (count <= 2) { nd.left = -1; nd.right = -1; nd.first = (int32_t)start; nd.count = (int32_t)count; return; }
+    double clo[3] = {1e30, 1e30, 1e30}, chi[3] = {-1e30, -1e30, -1e30};
+    for (size_t i = start; i < end; ++i)
+      for (int a = 0; a < 3; ++a) { double c = cen(prims[i], a); clo[a] = std::fmin(clo[a], c); chi[a] = std::fmax(chi[a], c); }
+    double dx = chi[0] - clo[0], dy = chi[1] - clo[1], dz = chi[2] - clo[2];
+    int axis = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);   // ref: bvh.hpp:100-107
+    size_t mid = start + count / 2;
+    std::nth_element(prims.begin() + start, prims.begin() + mid, prims.begin() + end,
+                     [axis](const BuildPrim& a, const BuildPrim& b) { return cen(a, axis) < cen(b, axis); });
+    size_t left = me + 1, right = me + 1 + subtree_nodes(mid - start);
+    nd.left = (int32_t)left; nd.right = (int32_t)right; nd.first = 0; nd.count = 0;
+    if (count > 32768 && depth < 4) {
+      auto fut = std::async(std::launch::async, [=] { build(left, start, mid, depth + 1); });
+      build(right, mid, end, depth + 1);
+      fut.get();
+    } else {
+      build(left, start, mid, depth + 1);
+      build(right, mid, end, depth + 1);
+    }
+  }
+};
+
+// round a double to float toward -inf / +inf
+float f_down(double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -INFINITY); return f; }
+float f_up(double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; }
+
+template <class T, class S> void cp3(T* dst, const S* src) { dst[0] = (T)src[0]; dst[1] = (T)src[1]; dst[2] = (T)src[2]; }
+
+template <class T> const T* push(std::vector<DeviceBuffer>& pool, const std::vector<T>& v, bool& ok) {
+  pool.emplace_back();
+  if (!pool.back().upload(v.data(), v.size() * sizeof(T))) ok = false;
+  return (const T*)pool.back().ptr;
+}
+
+// Luminance-weighted sampling tables of the environment map (ref: engine/texture.hpp:403-473).
+void build_env_tables(const rtx_environment& e, std::vector<double>& marginal, std::vector<double>& conditional, double& total) {
+  const double kPi = 3.14159265358979323846;
+  const int w = e.width, h = e.height;
+  marginal.assign(h + 1, 0.0);
+  conditional.assign((size_t)h * (w + 1), 0.0);
+  std::vector<double> rows(h);
+  for (int y = 0; y < h; ++y) {
+    double st = std::sin(kPi * (y + 0.5) / h);
+    double sum = 0.0;
+    size_t off = (size_t)y * (w + 1);
+    for (int x = 0; x < w; ++x) {
+      const float* t = e.rgb + ((size_t)y * w + x) * 3;
+      double lum = 0.2126 * t[0] + 0.7152 * t[1] + 0.0722 * t[2];
+      sum += lum * st;
+      conditional[off + x + 1] = sum;
+    }
+    if (sum > 0.0) for (int x = 1; x <= w; ++x) conditional[off + x] /= sum;
+    else for (int x = 1; x <= w; ++x) conditional[off + x] = (double)x / w;
+    rows[y] = sum;
+  }
+  for (int y = 0; y < h; ++y) marginal[y + 1] = marginal[y] + rows[y];
+  total = marginal[h];
+  if (total > 0.0) for (int y = 1; y <= h; ++y) marginal[y] /= total;
+  else for (int y = 1; y <= h; ++y) marginal[y] = (double)y / h;
+}
+
+template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& pool, const rtx_scene_desc& d, const HostBvh& bvh,
+                                   const std::vector<int32_t>& emissive, const DImage* d_images, const DPrimRef* d_prims,
+                                   const float* d_env_texels, const std::vector<double>& marginal, const std::vector<double>& conditional,
+                                   double env_total, bool& ok) {
+  memset(&sc, 0, sizeof sc);
+  std::vector<DSphere<R>> sph(d.n_spheres);
+  for (size_t i = 0; i < d.n_spheres; ++i) { cp3(sph[i].c, d.spheres[i].center); sph[i].radius = (R)d.spheres[i].radius; sph[i].mat = d.spheres[i].material_id; sph[i].pad = 0; }
+  std::vector<DPlane<R>> pls(d.n_planes);
+  for (size_t i = 0; i < d.n_planes; ++i) { cp3(pls[i].p, d.planes[i].point); cp3(pls[i].n, d.planes[i].normal); pls[i].mat = d.planes[i].material_id; pls[i].pad = 0; }
+  std::vector<DTri<R>> tris(d.n_triangles);
+  for (size_t i = 0; i < d.n_triangles; ++i) { cp3(tris[i].v0, d.triangles[i].v0); cp3(tris[i].v1, d.triangles[i].v1); cp3(tris[i].v2, d.triangles[i].v2); tris[i].mat = d.triangles[i].material_id; tris[i].pad = 0; }
+  std::vector<DBox<R>> boxes(d.n_boxes);
+  for (size_t i = 0; i < d.n_boxes; ++i) { cp3(boxes[i].lo, d.boxes[i].box_min); cp3(boxes[i].hi, d.boxes[i].box_max); boxes[i].mat = d.boxes[i].material_id; boxes[i].pad = 0; }
+  std::vector<DPoint<R>> pts(d.n_point_lights);
+  for (size_t i = 0; i < d.n_point_lights; ++i) { cp3(pts[i].pos, d.point_lights[i].position); cp3(pts[i].I, d.point_lights[i].intensity); }
+  std::vector<DQuad<R>> quads(d.n_quad_lights);
+  for (size_t i = 0; i < d.n_quad_lights; ++i) {
+    const rtx_quad_light& q = d.quad_lights[i];
+    cp3(quads[i].corner, q.corner); cp3(quads[i].eu, q.edge_u); cp3(quads[i].ev, q.edge_v); cp3(quads[i].n, q.normal); cp3(quads[i].Le, q.emission);
+    quads[i].area = (R)q.area;
+  }
+  std::vector<DDisk<R>> disks(d.n_disk_lights);
+  for (size_t i = 0; i < d.n_disk_lights; ++i) {
+    const rtx_disk_light& q = d.disk_lights[i];
+    cp3(disks[i].c, q.center); cp3(disks[i].n, q.normal); disks[i].radius = (R)q.radius; cp3(disks[i].Le, q.emission);
+    disks[i].area = (R)q.area; cp3(disks[i].tan, q.tangent); cp3(disks[i].bit, q.bitangent);
+  }
+  std::vector<DMaterial<R>> mats(d.n_materials);
+  for (size_t i = 0; i < d.n_materials; ++i) {
+    const rtx_material& m = d.materials[i];
+    mats[i].type = m.type; mats[i].has_texture = m.has_texture; mats[i].tex_type = m.tex_type; mats[i].tex_image = m.tex_image;
+    cp3(mats[i].albedo, m.albedo); cp3(mats[i].emission, m.emission); mats[i].fuzz = (R)m.fuzz; mats[i].ior = (R)m.refraction_index;
+    cp3(mats[i].c1, m.tex_color1); cp3(mats[i].c2, m.tex_color2); mats[i].scale = (R)m.tex_scale;
+  }
+  // Production BVH: the reference tree's topology, boxes in R.  Float boxes are rounded
+  // outward; a box that is flat in double stays flat so that the strict slab test rejects it
+  // exactly as the reference's does (a leaf of axis-aligned coplanar triangles is never hit there).
+  std::vector<DNode2<R>> nodes(bvh.nodes.size());
+  for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+    const DNodeRef& n = bvh.nodes[i];
+    for (int a = 0; a < 3; ++a) {
+      if (std::is_same<R, float>::value && n.lo[a] != n.hi[a]) { nodes[i].lo[a] = (R)f_down(n.lo[a]); nodes[i].hi[a] = (R)f_up(n.hi[a]); }
+      else { nodes[i].lo[a] = (R)n.lo[a]; nodes[i].hi[a] = (R)n.hi[a]; }
+    }
+    if (n.count > 0) { nodes[i].a = n.first; nodes[i].count = n.count; }
+    else { nodes[i].a = n.right; nodes[i].count = 0; }
+  }
+  sc.spheres = push(pool, sph, ok); sc.planes = push(pool, pls, ok); sc.tris = push(pool, tris, ok); sc.boxes = push(pool, boxes, ok);
+  sc.points = push(pool, pts, ok); sc.quads = push(pool, quads, ok); sc.disks = push(pool, disks, ok); sc.mats = push(pool, mats, ok);
+  sc.nodes = push(pool, nodes, ok);
+  sc.emissive = push(pool, emissive, ok);
+  sc.images = d_images; sc.prims = d_prims;
+  sc.n_spheres = (int)d.n_spheres; sc.n_planes = (int)d.n_planes; sc.n_tris = (int)d.n_triangles; sc.n_boxes = (int)d.n_boxes;
+  sc.n_points = (int)d.n_point_lights; sc.n_quads = (int)d.n_quad_lights; sc.n_disks = (int)d.n_disk_lights; sc.n_mats = (int)d.n_materials;
+  sc.n_images = (int)d.n_images; sc.n_emissive = (int)emissive.size();
+  sc.n_nodes = (int)bvh.nodes.size(); sc.n_prims = (int)bvh.prims.size();
+  if (d_env_texels) {
+    std::vector<R> mg(marginal.begin(), marginal.end()), cd(conditional.begin(), conditional.end());
+    sc.env.texel = d_env_texels;
+    sc.env.marginal = push(pool, mg, ok); sc.env.conditional = push(pool, cd, ok);
+    sc.env.w = d.environment->width; sc.env.h = d.environment->height;
+    sc.env.intensity = (R)d.environment->intensity; sc.env.rotation = (R)d.environment->rotation;
+    sc.env.valid = 1; sc.env.importance = env_total > 0.0 ? 1 : 0;   // ref: engine/texture.hpp:478-480, :692-694
+  }
+}
+
+}  // namespace
+
+void HostBvh::build(const rtx_scene_desc& d) {
+  auto t0 = std::chrono::steady_clock::now();
+  nodes.clear(); prims.clear();
+  std::vector<BuildPrim> bp;
+  bp.reserve(d.n_spheres + d.n_triangles + d.n_boxes);
+  for (size_t i = 0; i < d.n_spheres; ++i) {   // ref: engine/scene.hpp:500-510
+    BuildPrim p; p.type = PRIM_SPHERE; p.index = (int32_t)i;
+    for (int a = 0; a < 3; ++a) { p.lo[a] = d.spheres[i].center[a] - d.spheres[i].radius; p.hi[a] = d.spheres[i].center[a] + d.spheres[i].radius; }
+    bp.push_back(p);
+  }
+  for (size_t i = 0; i < d.n_triangles; ++i) {  // ref: engine/scene.hpp:513-522
+    BuildPrim p; p.type = PRIM_TRIANGLE; p.index = (int32_t)i;
+    const rtx_triangle& t = d.triangles[i];
+    for (int a = 0; a < 3; ++a) {
+      p.lo[a] = std::fmin(std::fmin(std::fmin(1e30, t.v0[a]), t.v1[a]), t.v2[a]);
+      p.hi[a] = std::fmax(std::fmax(std::fmax(-1e30, t.v0[a]), t.v1[a]), t.v2[a]);
+    }
+    bp.push_back(p);
+  }
+  for (size_t i = 0; i < d.n_boxes; ++i) {      // ref: engine/scene.hpp:525-533
+    BuildPrim p; p.type = PRIM_BOX; p.index = (int32_t)i;
+    for (int a = 0; a < 3; ++a) { p.lo[a] = d.boxes[i].box_min[a]; p.hi[a] = d.boxes[i].box_max[a]; }
+    bp.push_back(p);
+  }
+  if (!bp.empty()) {
+    nodes.resize(subtree_nodes(bp.size()));
+    Builder b{bp, nodes};
+    b.build(0, 0, bp.size(), 0);
+    prims.resize(bp.size());
+    for (size_t i = 0; i < bp.size(); ++i) { prims[i].type = bp[i].type; prims[i].index = bp[i].index; }
+  }
+  seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void HostScene::release() {
+  for (DeviceBuffer& b : pool) b.release();
+  pool.clear();
+  memset(&dev_f, 0, sizeof dev_f); memset(&dev_d, 0, sizeof dev_d); memset(&dev_ref, 0, sizeof dev_ref);
+  n_nodes = n_prims = 0;
+}
+
+int HostScene::upload(const rtx_scene_desc& d, std::string& err) {
+  release();
+  const size_t lim = 0x7fffffff;
+  if (d.n_spheres > lim || d.n_planes > lim || d.n_triangles > lim || d.n_boxes > lim || d.n_materials > lim ||
+      d.n_spheres + d.n_triangles + d.n_boxes > lim / 2) { err = "too many primitives"; return RTX_ERR_INVALID_ARGUMENT; }
+  auto need = [&](const void* p, size_t n, const char* what) { if (n && !p) { err = std::string(what) + " is NULL"; return false; } return true; };
+  if (!need(d.spheres, d.n_spheres, "spheres") || !need(d.planes, d.n_planes, "planes") || !need(d.triangles, d.n_triangles, "triangles") ||
+      !need(d.boxes, d.n_boxes, "boxes") || !need(d.point_lights, d.n_point_lights, "point_lights") || !need(d.quad_lights, d.n_quad_lights, "quad_lights") ||
+      !need(d.disk_lights, d.n_disk_lights, "disk_lights") || !need(d.materials, d.n_materials, "materials") || !need(d.images, d.n_images, "images"))
+    return RTX_ERR_INVALID_ARGUMENT;
+  // The reference indexes its material array unchecked (engine/scene.hpp:705-707); an id out
+  // of range would be a device fault here, so it is rejected up front.
+  const int nm = (int)d.n_materials;
+  auto bad = [&](int id) { return id < 0 || id >= nm; };
+  for (size_t i = 0; i < d.n_spheres; ++i) if (bad(d.spheres[i].material_id)) { err = "sphere material id out of range"; return RTX_ERR_INVALID_ARGUMENT; }
+  for (size_t i = 0; i < d.n_planes; ++i) if (bad(d.planes[i].material_id)) { err = "plane material id out of range"; return RTX_ERR_INVALID_ARGUMENT; }
+  for (size_t i = 0; i < d.n_triangles; ++i) if (bad(d.triangles[i].material_id)) { err = "triangle material id out of range"; return RTX_ERR_INVALID_ARGUMENT; }
+  for (size_t i = 0; i < d.n_boxes; ++i) if (bad(d.boxes[i].material_id)) { err = "box material id out of range"; return RTX_ERR_INVALID_ARGUMENT; }
+  for (size_t i = 0; i < d.n_materials; ++i) {
+    const rtx_material& m = d.materials[i];
+    if (m.type < 0 || m.type > 2) { err = "material type out of range"; return RTX_ERR_INVALID_ARGUMENT; }
+    if (m.has_texture && m.tex_type == RTX_TEX_IMAGE && (m.tex_image < 0 || (size_t)m.tex_image >= d.n_images)) { err = "material image index out of range"; return RTX_ERR_INVALID_ARGUMENT; }
+  }
+  for (size_t i = 0; i < d.n_images; ++i) if (!d.images[i].rgb || d.images[i].width <= 0 || d.images[i].height <= 0) { err = "bad image"; return RTX_ERR_INVALID_ARGUMENT; }
+
+  HostBvh bvh;
+  bvh.build(d);
+  build_seconds = bvh.seconds;
+  n_nodes = (int)bvh.nodes.size(); n_prims = (int)bvh.prims.size();
+
+  std::vector<int32_t> emissive;   // ref: engine/scene.hpp:222-230
+  for (size_t i = 0; i < d.n_spheres; ++i) {
+    const rtx_material& m = d.materials[d.spheres[i].material_id];
+    if (m.emission[0] > 0.0 || m.emission[1] > 0.0 || m.emission[2] > 0.0) emissive.push_back((int32_t)i);
+  }
+
+  bool ok = true;
+  std::vector<DImage> imgs(d.n_images);
+  for (size_t i = 0; i < d.n_images; ++i) {
+    pool.emplace_back();
+    if (!pool.back().upload(d.images[i].rgb, (size_t)d.images[i].width * d.images[i].height * 3)) ok = false;
+    imgs[i].rgb = (const uint8_t*)pool.back().ptr; imgs[i].w = d.images[i].width; imgs[i].h = d.images[i].height;
+  }
+  const DImage* d_images = push(pool, imgs, ok);
+  const DPrimRef* d_prims = push(pool, bvh.prims, ok);
+  const DNodeRef* d_nodes_ref = push(pool, bvh.nodes, ok);
+
+  const float* d_env = nullptr;
+  std::vector<double> marginal, conditional;
+  double env_total = 0.0;
+  const rtx_environment* e = d.environment;
+  if (e && e->rgb && e->width > 0 && e->height > 0) {
+    build_env_tables(*e, marginal, conditional, env_total);
+    pool.emplace_back();
+    if (!pool.back().upload(e->rgb, (size_t)e->width * e->height * 3 * sizeof(float))) ok = false;
+    d_env = (const float*)pool.back().ptr;
+  }
+  fill_scene(dev_d, pool, d, bvh, emissive, d_images, d_prims, d_env, marginal, conditional, env_total, ok);
+  fill_scene(dev_f, pool, d, bvh, emissive, d_images, d_prims, d_env, marginal, conditional, env_total, ok);
+  dev_ref.nodes = d_nodes_ref; dev_ref.prims = d_prims; dev_ref.n_nodes = n_nodes; dev_ref.n_prims = n_prims;
+  if (!ok) { release(); err = "device allocation or copy failed"; return RTX_ERR_OUT_OF_MEMORY; }
+  return RTX_OK;
+}
+
+}  // namespace rtx

@@ -1,0 +1,62 @@
+// Host-side helpers of the backend: device buffers, the uploaded scene, kernel launchers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rtx_hip.h"
+#include "pt_types.hpp"
+
+namespace rtx {
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t bytes);   // grow-only; contents are NOT preserved on growth
+  bool upload(const void* src, size_t bytes);
+  void release();
+};
+
+// The reference-order BVH on the host (ref: engine/bvh.hpp:148-218 over the primitive list
+// of engine/scene.hpp:496-533).
+struct HostBvh {
+  std::vector<DNodeRef> nodes;
+  std::vector<DPrimRef> prims;
+  double seconds = 0.0;
+  void build(const rtx_scene_desc& d);
+};
+
+struct HostScene {
+  DScene<float> dev_f;
+  DScene<double> dev_d;
+  DSceneRef dev_ref;
+  int n_nodes = 0, n_prims = 0;
+  double build_seconds = 0.0;
+  std::vector<DeviceBuffer> pool;   // owns every device allocation of the scene
+  int upload(const rtx_scene_desc& d, std::string& err);
+  void release();
+};
+
+// kernel launchers (kernels_f32.hip / kernels_f64.hip)
+void launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
+                         int grid, size_t lds_bytes, hipStream_t stream);
+void launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters,
+                         int grid, size_t lds_bytes, hipStream_t stream);
+void launch_film_reduce(const float* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream);
+void launch_film_reduce(const double* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream);
+void launch_trace_fast(const DScene<float>& sc, const double* rays8, unsigned long long n, DHitOut* out, size_t lds_bytes, hipStream_t stream);
+void launch_trace_fast(const DScene<double>& sc, const double* rays8, unsigned long long n, DHitOut* out, size_t lds_bytes, hipStream_t stream);
+void launch_trace_ref(const DScene<double>& sc, const DSceneRef& ref, const double* rays8, unsigned long long n, DHitOut* out, hipStream_t stream);
+void launch_selftest(float* out, int n, hipStream_t stream);
+
+// Wavefront pipeline (wavefront.hip): queue storage + the per-iteration launch loop.
+struct WavefrontPool {
+  DeviceBuffer state, queues, control;
+  void release();
+};
+int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* d_film,
+                     DCounters* counters, int n_cus, bool needs_stack, hipStream_t stream, uint32_t& launches, std::string& err);
+
+}  // namespace rtx

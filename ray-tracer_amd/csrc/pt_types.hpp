@@ -1,0 +1,85 @@
+// Device-side scene layout shared by the host uploader and the gfx950 kernels.
+//
+// Everything is templated on the arithmetic type R: double instantiations hold exactly the
+// bits the caller passed through rtx_scene_desc (validation / parity mode), float
+// instantiations are the production layout.
+#pragma once
+
+#include <stdint.h>
+
+namespace rtx {
+
+template <class R> struct DSphere { R c[3]; R radius; int32_t mat; int32_t pad; };
+template <class R> struct DPlane { R p[3]; R n[3]; int32_t mat; int32_t pad; };
+template <class R> struct DTri { R v0[3], v1[3], v2[3]; int32_t mat; int32_t pad; };
+template <class R> struct DBox { R lo[3], hi[3]; int32_t mat; int32_t pad; };
+template <class R> struct DPoint { R pos[3], I[3]; };
+template <class R> struct DQuad { R corner[3], eu[3], ev[3], n[3], Le[3]; R area; };
+template <class R> struct DDisk { R c[3], n[3]; R radius; R Le[3]; R area; R tan[3], bit[3]; };
+
+template <class R> struct DMaterial {
+  int32_t type, has_texture, tex_type, tex_image;
+  R albedo[3], emission[3], fuzz, ior, c1[3], c2[3], scale;
+};
+
+struct DImage { const uint8_t* rgb; int32_t w, h; };
+
+// Reference-order binary BVH node: the members of BVHNode (engine/bvh.hpp:124-130).
+struct DNodeRef { double lo[3], hi[3]; int32_t left, right, first, count; };
+struct DPrimRef { int32_t type, index; };
+
+// Production BVH node (32 bytes in float): the same binary topology in preorder, so the
+// left child of node i is i+1.  count > 0: leaf over prims[a .. a+count); else a = right child.
+template <class R> struct DNode2 { R lo[3], hi[3]; int32_t a, count; };
+
+template <class R> struct DEnv {
+  const float* texel;        // RGB, row 0 = top
+  const R* marginal;         // h+1
+  const R* conditional;      // h*(w+1)
+  int32_t w, h;
+  R intensity, rotation;
+  int32_t valid, importance; // EnvironmentMap::valid() / has_importance_sampling()
+};
+
+template <class R> struct DScene {
+  const DSphere<R>* spheres; const DPlane<R>* planes; const DTri<R>* tris; const DBox<R>* boxes;
+  const DPoint<R>* points; const DQuad<R>* quads; const DDisk<R>* disks; const DMaterial<R>* mats;
+  const DImage* images; const int32_t* emissive;   // indices of emissive spheres, ascending
+  const DNode2<R>* nodes; const DPrimRef* prims;    // production BVH + primitive order (reference leaf order)
+  int32_t n_spheres, n_planes, n_tris, n_boxes, n_points, n_quads, n_disks, n_mats, n_images, n_emissive;
+  int32_t n_nodes, n_prims;
+  DEnv<R> env;
+};
+
+struct DSceneRef {  // validation BVH, always double
+  const DNodeRef* nodes; const DPrimRef* prims; int32_t n_nodes, n_prims;
+};
+
+template <class R> struct DCamera { R origin[3], llc[3], horizontal[3], vertical[3]; };
+
+struct DRenderParams {
+  int32_t width, height, spp, max_depth;
+  int32_t use_nee, use_mis, use_gradient;
+  int32_t shard_index, shard_count, rows;  // rows = rows owned by this shard
+  int32_t n_chunks, chunk_spp;             // samples are summed in fixed chunks (deterministic film)
+  uint32_t seed;
+  double bg[3], bg_top[3], bg_bottom[3];
+};
+
+struct DCounters { unsigned long long samples, closest, shadow, segments; };
+
+// One closest-hit answer in the layout of rtx_hit (include/rtx_hip.h).
+struct DHitOut {
+  int32_t hit, prim_type, prim_index, material_id, front_face, pad;
+  double t, point[3], normal[3], u, v;
+};
+
+constexpr int kBlock = 256;          // threads per workgroup of the render / trace kernels
+constexpr int kLinearMaxPrims = 12;  // at or below this many bounded primitives: no tree walk
+constexpr int kStackDepth = 48;      // per-lane traversal stack entries (LDS)
+
+enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_TRIANGLE = 2, PRIM_BOX = 3, PRIM_QUAD = 4, PRIM_DISK = 5 };
+enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2 };
+enum { TEX_SOLID = 0, TEX_CHECKER = 1, TEX_IMAGE = 2 };
+
+}  // namespace rtx

@@ -1,0 +1,268 @@
+// Host side of the C ABI declared in include/rtx_hip.h: context, scene upload (both BVHs,
+// environment tables, float/double device copies), kernel launches, error reporting.
+#include "../../include/rtx_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pt_host.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(e_ == hipErrorOutOfMemory ? RTX_ERR_OUT_OF_MEMORY : RTX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+}  // namespace
+
+using namespace rtx;
+
+struct rtx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int n_cus = 256;
+  bool has_scene = false, has_camera = false;
+  HostScene scene;          // device-resident copies + BVHs
+  DCamera<float> cam_f;
+  DCamera<double> cam_d;
+  DeviceBuffer partial, film, counters, rays, hits;
+  WavefrontPool wf;         // wavefront-pipeline queues, allocated on first use
+};
+
+extern "C" {
+
+const char* rtx_last_error(void) { return g_error.c_str(); }
+
+int rtx_shard_rows(int height, int shard_index, int shard_count) {
+  if (shard_count <= 0 || shard_index < 0 || shard_index >= shard_count || height <= 0) return 0;
+  return (height - shard_index + shard_count - 1) / shard_count;
+}
+
+int rtx_selftest(int device_id) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return fail(RTX_ERR_NO_DEVICE, "no HIP device visible");
+  if (device_id < 0 || device_id >= n_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device_id, n_dev);
+  HIP_TRY(hipSetDevice(device_id));
+  const int n = 1024;
+  float* d = nullptr;
+  HIP_TRY(hipMalloc(&d, n * sizeof(float)));
+  launch_selftest(d, n, nullptr);
+  std::vector<float> h(n);
+  hipError_t e = hipMemcpy(h.data(), d, n * sizeof(float), hipMemcpyDeviceToHost);
+  hipFree(d);
+  if (e != hipSuccess) return fail(RTX_ERR_HIP, "selftest copy: %s", hipGetErrorString(e));
+  for (int i : {0, 1, 1023})
+    if (std::fabs(h[i] - (float)i * 0.001f) > 1e-6f) return fail(RTX_ERR_HIP, "selftest: out[%d] = %g", i, h[i]);
+  return RTX_OK;
+}
+
+int rtx_create(rtx_ctx** out_ctx, int device_id) {
+  if (!out_ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return fail(RTX_ERR_NO_DEVICE, "no HIP device visible");
+  if (device_id < 0 || device_id >= n_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device_id, n_dev);
+  HIP_TRY(hipSetDevice(device_id));
+  rtx_ctx* c = new rtx_ctx();
+  c->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount;
+  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return fail(RTX_ERR_HIP, "stream/event creation failed");
+  }
+  *out_ctx = c;
+  return RTX_OK;
+}
+
+int rtx_destroy(rtx_ctx* c) {
+  if (!c) return RTX_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  c->scene.release();
+  c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release();
+  c->wf.release();
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return RTX_OK;
+}
+
+int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d) {
+  if (!c || !d) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  std::string err;
+  int rc = c->scene.upload(*d, err);
+  if (rc != RTX_OK) { c->has_scene = false; return fail(rc, "upload_scene: %s", err.c_str()); }
+  c->has_scene = true;
+  return RTX_OK;
+}
+
+int rtx_set_camera(rtx_ctx* c, const rtx_camera* cam) {
+  if (!c || !cam) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+  for (int i = 0; i < 3; ++i) {
+    c->cam_d.origin[i] = cam->origin[i]; c->cam_d.llc[i] = cam->lower_left_corner[i];
+    c->cam_d.horizontal[i] = cam->horizontal[i]; c->cam_d.vertical[i] = cam->vertical[i];
+    c->cam_f.origin[i] = (float)cam->origin[i]; c->cam_f.llc[i] = (float)cam->lower_left_corner[i];
+    c->cam_f.horizontal[i] = (float)cam->horizontal[i]; c->cam_f.vertical[i] = (float)cam->vertical[i];
+  }
+  c->has_camera = true;
+  return RTX_OK;
+}
+
+int rtx_get_bvh_info(rtx_ctx* c, rtx_bvh_info* out) {
+  if (!c || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "no scene uploaded");
+  out->ref_nodes = c->scene.n_nodes; out->ref_prims = c->scene.n_prims;
+  out->wide_nodes = c->scene.n_nodes; out->wide_bytes = (uint64_t)c->scene.n_nodes * sizeof(DNode2<float>);
+  out->build_seconds = c->scene.build_seconds;
+  return RTX_OK;
+}
+
+static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, rtx_stats* stats) {
+  if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "render before upload_scene");
+  if (!c->has_camera) return fail(RTX_ERR_NOT_READY, "render before set_camera");
+  if (s->width <= 0 || s->height <= 0 || s->samples_per_pixel <= 0 || s->max_depth < 0)
+    return fail(RTX_ERR_INVALID_ARGUMENT, "bad settings: %dx%d spp=%d depth=%d", s->width, s->height, s->samples_per_pixel, s->max_depth);
+  if ((long long)s->width * s->height > 0x7fffffffLL) return fail(RTX_ERR_INVALID_ARGUMENT, "film too large");
+  if (s->use_mnee) return fail(RTX_ERR_UNSUPPORTED, "use_mnee: manifold next-event estimation is not implemented by this backend");
+  const int sc_n = s->shard_count > 0 ? s->shard_count : 1;
+  if (s->shard_index < 0 || s->shard_index >= sc_n) return fail(RTX_ERR_INVALID_ARGUMENT, "shard %d of %d", s->shard_index, sc_n);
+  if (s->precision != RTX_PRECISION_F32 && s->precision != RTX_PRECISION_F64) return fail(RTX_ERR_INVALID_ARGUMENT, "precision %d", s->precision);
+  if (s->pipeline < RTX_PIPELINE_AUTO || s->pipeline > RTX_PIPELINE_WAVEFRONT) return fail(RTX_ERR_INVALID_ARGUMENT, "pipeline %d", s->pipeline);
+  if (!host_out && !dev_out) return fail(RTX_ERR_INVALID_ARGUMENT, "output buffer is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  auto wall0 = std::chrono::steady_clock::now();
+  hipStream_t stream = user_stream ? user_stream : c->stream;
+
+  DRenderParams P;
+  memset(&P, 0, sizeof P);
+  P.width = s->width; P.height = s->height; P.spp = s->samples_per_pixel; P.max_depth = s->max_depth;
+  P.use_nee = s->use_nee != 0; P.use_mis = s->use_mis != 0; P.use_gradient = s->use_background_gradient != 0;
+  P.shard_index = s->shard_index; P.shard_count = sc_n;
+  P.rows = rtx_shard_rows(s->height, s->shard_index, sc_n);
+  // Fixed chunking of the sample sum (a function of spp only) keeps the film bit-identical
+  // for any grid size or shard count.
+  int target_chunks = std::min(P.spp, 16);
+  P.chunk_spp = (P.spp + target_chunks - 1) / target_chunks;
+  P.n_chunks = (P.spp + P.chunk_spp - 1) / P.chunk_spp;
+  P.seed = s->seed;
+  for (int i = 0; i < 3; ++i) { P.bg[i] = s->background_color[i]; P.bg_top[i] = s->background_top[i]; P.bg_bottom[i] = s->background_bottom[i]; }
+
+  const unsigned long long npix = (unsigned long long)P.rows * P.width;
+  rtx_stats st;
+  memset(&st, 0, sizeof st);
+  if (npix == 0) { if (stats) *stats = st; return RTX_OK; }
+  const bool f64 = s->precision == RTX_PRECISION_F64;
+  int pipeline = s->pipeline == RTX_PIPELINE_AUTO ? RTX_PIPELINE_FUSED : s->pipeline;
+  if (pipeline == RTX_PIPELINE_WAVEFRONT && f64) return fail(RTX_ERR_UNSUPPORTED, "the wavefront pipeline is single precision only");
+
+  float* d_film = (float*)dev_out;
+  if (!d_film) {
+    if (!c->film.ensure(npix * 3 * sizeof(float))) return fail(RTX_ERR_OUT_OF_MEMORY, "film buffer");
+    d_film = (float*)c->film.ptr;
+  }
+  if (!c->counters.ensure(sizeof(DCounters))) return fail(RTX_ERR_OUT_OF_MEMORY, "counters");
+  HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DCounters), stream));
+
+  const bool needs_stack = c->scene.n_prims > kLinearMaxPrims;
+  HIP_TRY(hipEventRecord(c->ev0, stream));
+  if (pipeline == RTX_PIPELINE_FUSED) {
+    const size_t elem = f64 ? sizeof(double) : sizeof(float);
+    if (!c->partial.ensure((size_t)P.n_chunks * npix * 3 * elem)) return fail(RTX_ERR_OUT_OF_MEMORY, "chunk-sum buffer (%llu bytes)", (unsigned long long)((size_t)P.n_chunks * npix * 3 * elem));
+    const unsigned long long items = npix * (unsigned long long)P.n_chunks;
+    const size_t lds = needs_stack ? (size_t)kStackDepth * kBlock * sizeof(int) : 0;
+    // Persistent grid: enough blocks to fill every CU at the kernel's occupancy, no more.
+    const int blocks_per_cu = needs_stack ? 3 : 4;
+    int grid = (int)std::min<unsigned long long>((items + kBlock - 1) / kBlock, (unsigned long long)c->n_cus * blocks_per_cu);
+    if (f64) {
+      launch_render_fused(c->scene.dev_d, c->cam_d, P, (double*)c->partial.ptr, (DCounters*)c->counters.ptr, grid, lds, stream);
+      launch_film_reduce((const double*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
+    } else {
+      launch_render_fused(c->scene.dev_f, c->cam_f, P, (float*)c->partial.ptr, (DCounters*)c->counters.ptr, grid, lds, stream);
+      launch_film_reduce((const float*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
+    }
+    st.kernel_launches = 2;
+  } else {
+    std::string err;
+    int rc = wavefront_render(c->wf, c->scene.dev_f, c->cam_f, P, d_film, (DCounters*)c->counters.ptr, c->n_cus, needs_stack, stream, st.kernel_launches, err);
+    if (rc != RTX_OK) return fail(rc, "wavefront: %s", err.c_str());
+  }
+  HIP_TRY(hipEventRecord(c->ev1, stream));
+  HIP_TRY(hipGetLastError());
+  DCounters hc;
+  HIP_TRY(hipMemcpyAsync(&hc, c->counters.ptr, sizeof hc, hipMemcpyDeviceToHost, stream));
+  if (host_out) HIP_TRY(hipMemcpyAsync(host_out, d_film, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  st.samples = hc.samples; st.rays_closest = hc.closest; st.rays_shadow = hc.shadow; st.segments = hc.segments;
+  st.seconds_render = ms * 1e-3;
+  st.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+  st.pipeline_used = (uint32_t)pipeline;
+  if (stats) *stats = st;
+  return RTX_OK;
+}
+
+int rtx_render(rtx_ctx* c, const rtx_settings* s, float* out_rgb, rtx_stats* stats) {
+  if (!out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "out_rgb is NULL");
+  return render_impl(c, s, out_rgb, nullptr, nullptr, stats);
+}
+
+int rtx_render_device(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* hip_stream, rtx_stats* stats) {
+  if (!d_out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "d_out_rgb is NULL");
+  return render_impl(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, stats);
+}
+
+static int trace_impl(rtx_ctx* c, const double* rays8, size_t n, rtx_hit* out, int mode /*0 ref, 1 fast f32, 2 fast f64*/) {
+  if (!c || (!rays8 && n) || (!out && n)) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "trace before upload_scene");
+  if (n == 0) return RTX_OK;
+  static_assert(sizeof(DHitOut) == sizeof(rtx_hit), "hit layouts must agree");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->rays.ensure(n * 8 * sizeof(double)) || !c->hits.ensure(n * sizeof(DHitOut))) return fail(RTX_ERR_OUT_OF_MEMORY, "ray batch of %zu", n);
+  HIP_TRY(hipMemcpyAsync(c->rays.ptr, rays8, n * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const size_t lds = c->scene.n_prims > kLinearMaxPrims ? (size_t)kStackDepth * kBlock * sizeof(int) : 0;
+  if (mode == 0) launch_trace_ref(c->scene.dev_d, c->scene.dev_ref, (const double*)c->rays.ptr, n, (DHitOut*)c->hits.ptr, c->stream);
+  else if (mode == 1) launch_trace_fast(c->scene.dev_f, (const double*)c->rays.ptr, n, (DHitOut*)c->hits.ptr, lds, c->stream);
+  else launch_trace_fast(c->scene.dev_d, (const double*)c->rays.ptr, n, (DHitOut*)c->hits.ptr, lds, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, c->hits.ptr, n * sizeof(DHitOut), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTX_OK;
+}
+
+int rtx_trace_closest(rtx_ctx* c, const double* rays8, size_t n, rtx_hit* out) { return trace_impl(c, rays8, n, out, 0); }
+
+int rtx_trace_closest_fast(rtx_ctx* c, const double* rays8, size_t n, int precision, rtx_hit* out) {
+  if (precision != RTX_PRECISION_F32 && precision != RTX_PRECISION_F64) return fail(RTX_ERR_INVALID_ARGUMENT, "precision %d", precision);
+  return trace_impl(c, rays8, n, out, precision == RTX_PRECISION_F32 ? 1 : 2);
+}
+
+}  // extern "C"

@@ -1,0 +1,150 @@
+"""Host-side mirror of the reference's renderer-facing interfaces, bound to the HIP library.
+
+`HipPathTracer` has the method names, call order and output convention of the reference's
+GPU plug-in ``raytracer::cuda::GPUPathTracer`` (engine/cuda/cuda_api.hpp:72-110):
+``set_settings`` -> ``upload_scene`` -> ``set_camera`` -> ``render``.  `render_scene` plays
+the role of the PathTrace branch of ``Renderer::render`` (engine/renderer.cpp:263-481) and
+`tone_map` / `quantize` the post-process of engine/renderer.cpp:102-261.
+
+Every entry point goes through the C ABI of include/rtx_hip.h; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .scene_loader import SceneData, TM_ACES, TM_NONE, TM_REINHARD, TM_REINHARD_EXT, TM_UNCHARTED2
+
+HIT_DTYPE = np.dtype([("hit", "<i4"), ("prim_type", "<i4"), ("prim_index", "<i4"), ("material_id", "<i4"),
+                      ("front_face", "<i4"), ("pad_", "<i4"), ("t", "<f8"), ("point", "<f8", 3), ("normal", "<f8", 3),
+                      ("u", "<f8"), ("v", "<f8")])
+
+
+class HipPathTracer:
+    def __init__(self, device_id: int = 0):
+        self._lib = abi.load_library()
+        self._ctx = C.c_void_p()
+        abi.check(self._lib, self._lib.rtx_create(C.byref(self._ctx), device_id), "rtx_create")
+        self._settings: abi.Settings | None = None
+        self._scene_keepalive = None
+        self.last_stats: abi.Stats | None = None
+
+    def close(self):
+        if self._ctx:
+            self._lib.rtx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- GPUPathTracer surface -------------------------------------------------------------
+    def set_settings(self, settings: abi.Settings):
+        self._settings = settings
+
+    def upload_scene(self, scene: SceneData):
+        desc = scene.desc()
+        self._scene_keepalive = (scene, desc)
+        abi.check(self._lib, self._lib.rtx_upload_scene(self._ctx, C.byref(desc)), "rtx_upload_scene")
+
+    def set_camera(self, camera: abi.Camera):
+        abi.check(self._lib, self._lib.rtx_set_camera(self._ctx, C.byref(camera)), "rtx_set_camera")
+
+    def render(self, output: np.ndarray | None = None) -> np.ndarray:
+        """Render with the current settings into `output` (float32, rows_of_shard*W*3); returns
+        it shaped [rows, W, 3], row 0 = bottom."""
+        st = self._settings
+        if st is None:
+            raise abi.RtxError("render before set_settings")
+        rows = self._lib.rtx_shard_rows(st.height, st.shard_index, max(1, st.shard_count))
+        if output is None:
+            output = np.empty((rows, st.width, 3), dtype=np.float32)
+        assert output.dtype == np.float32 and output.size == rows * st.width * 3 and output.flags.c_contiguous
+        stats = abi.Stats()
+        abi.check(self._lib, self._lib.rtx_render(self._ctx, C.byref(st), output.ctypes.data_as(C.POINTER(C.c_float)), C.byref(stats)), "rtx_render")
+        self.last_stats = stats
+        return output.reshape(rows, st.width, 3)
+
+    # -- additions of this backend -----------------------------------------------------------
+    def render_device(self, device_ptr: int, stream: int = 0) -> abi.Stats:
+        """Render into device memory (e.g. a torch tensor's data_ptr on this device)."""
+        st = self._settings
+        if st is None:
+            raise abi.RtxError("render before set_settings")
+        stats = abi.Stats()
+        abi.check(self._lib, self._lib.rtx_render_device(self._ctx, C.byref(st), C.c_void_p(device_ptr), C.c_void_p(stream), C.byref(stats)), "rtx_render_device")
+        self.last_stats = stats
+        return stats
+
+    def trace_closest(self, rays8: np.ndarray, fast_precision: int | None = None) -> np.ndarray:
+        """Closest hits for rays [n, 8] = (origin, direction, t_min, t_max).  Default: the
+        double-precision reference-order kernel; fast_precision selects the production BVH."""
+        rays8 = np.ascontiguousarray(rays8, dtype=np.float64).reshape(-1, 8)
+        out = np.zeros(rays8.shape[0], dtype=HIT_DTYPE)
+        rp = rays8.ctypes.data_as(C.POINTER(C.c_double))
+        op = C.cast(out.ctypes.data, C.POINTER(abi.Hit))
+        if fast_precision is None:
+            abi.check(self._lib, self._lib.rtx_trace_closest(self._ctx, rp, rays8.shape[0], op), "rtx_trace_closest")
+        else:
+            abi.check(self._lib, self._lib.rtx_trace_closest_fast(self._ctx, rp, rays8.shape[0], fast_precision, op), "rtx_trace_closest_fast")
+        return out
+
+    def bvh_info(self) -> abi.BvhInfo:
+        info = abi.BvhInfo()
+        abi.check(self._lib, self._lib.rtx_get_bvh_info(self._ctx, C.byref(info)), "rtx_get_bvh_info")
+        return info
+
+
+def test_hip(device_id: int = 0) -> bool:
+    """Counterpart of raytracer::cuda::test_cuda() (engine/cuda/cuda_api.hpp:17)."""
+    lib = abi.load_library()
+    return lib.rtx_selftest(device_id) == 0
+
+
+def render_scene(scene: SceneData, device_id: int = 0, **settings_overrides) -> tuple[np.ndarray, abi.Stats]:
+    """Load-to-film convenience: the PathTrace branch of Renderer::render on the GPU.
+    Returns the linear film [H, W, 3] (row 0 = bottom) and the backend's statistics."""
+    st = scene.settings(**settings_overrides)
+    with HipPathTracer(device_id) as pt:
+        pt.set_settings(st)
+        pt.upload_scene(scene)
+        pt.set_camera(scene.camera(st.width, st.height))
+        film = pt.render()
+        return film, pt.last_stats
+
+
+# ---- post-process (engine/renderer.cpp:102-261) ---------------------------------------------
+def tone_map(film: np.ndarray, mapper: int = TM_ACES, exposure: float = 1.0) -> np.ndarray:
+    """Image::apply_tone_mapping (engine/renderer.cpp:186-198) in double precision."""
+    c = film.astype(np.float64) * exposure
+    if mapper == TM_REINHARD:
+        return c / (1.0 + c)
+    if mapper == TM_REINHARD_EXT:
+        wp2 = 4.0 * 4.0
+        return c * (1.0 + c / wp2) / (1.0 + c)
+    if mapper == TM_ACES:
+        a, b, cc, d, e = 2.51, 0.03, 2.43, 0.59, 0.14
+        return np.clip((c * (a * c + b)) / (c * (cc * c + d) + e), 0.0, 1.0)
+    if mapper == TM_UNCHARTED2:
+        def part(x):
+            A, B, Cc, D, E, F = 0.15, 0.50, 0.10, 0.20, 0.02, 0.30
+            return ((x * (A * x + Cc * B) + D * E) / (x * (A * x + B) + D * F)) - E / F
+        return part(c * 2.0) * (1.0 / part(11.2))
+    return np.clip(c, 0.0, 1.0)  # ToneMapper::None still clamps (renderer.cpp:175-182)
+
+
+def quantize(mapped: np.ndarray) -> np.ndarray:
+    """sqrt gamma, 255.999 quantisation and the vertical flip of Image::write_png
+    (engine/renderer.cpp:232-258): returns uint8 [H, W, 3] with row 0 = TOP."""
+    g = np.sqrt(np.clip(mapped, 0.0, 1.0))
+    return (255.999 * g).astype(np.int32).astype(np.uint8)[::-1].copy()
