@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Cornell box path tracing with NEE + MIS on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one complete render of the workload (default: scenes/cornell_box.json at
+1920x1080, 1024 spp, max_depth 500, NEE + MIS, manifold NEE off — the configuration the
+headline metric is quoted on).  With N > 1 (launched by torch.distributed.run, one rank per
+GPU) the image's rows are interleaved over the ranks and the film is gathered to rank 0
+over RCCL inside the timed region; total work is fixed, so scaling is "strong".
+
+Rank 0 prints ONE JSON line.  `value` = samples of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E peak (spec)
+# Algorithmic bytes of a wavefront path tracer per unit of work: path state written + read
+# (96 B) + hit record (32 B) + two queue indices (16 B) per path segment; 88 B per shadow ray;
+# 24 B of film accumulation per sample.
+BYTES_PER_SEGMENT, BYTES_PER_SHADOW_RAY, BYTES_PER_SAMPLE = 144, 88, 24
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "scenes", "cornell_box.json"))
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--max-depth", type=int, default=500)
+    ap.add_argument("--pipeline", choices=["auto", "fused", "wavefront"], default="auto")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import rtx_pkg
+    pkg = rtx_pkg.load()
+    import importlib
+    parallel = importlib.import_module("raytracer_amd.parallel")
+    abi = pkg.abi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} disagrees with WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    sd = pkg.scene_loader.load(args.scene)
+    W, H, spp = args.width, args.height, args.spp
+    pipeline = {"auto": abi.PIPELINE_AUTO, "fused": abi.PIPELINE_FUSED, "wavefront": abi.PIPELINE_WAVEFRONT}[args.pipeline]
+    st = sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=args.max_depth, use_nee=1, use_mis=1, seed=1234,
+                     precision=abi.PRECISION_F32, pipeline=pipeline, shard_index=rank, shard_count=world)
+    pt = pkg.renderer.HipPathTracer(local_rank)
+    pt.set_settings(st)
+    pt.upload_scene(sd)                       # inputs are resident in HBM before the timed region
+    pt.set_camera(sd.camera(W, H))
+    rows = parallel.shard_rows(H, rank, world)
+    local = torch.empty((rows, W, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    stats = []
+
+    def step():
+        s = pt.render_device(local.data_ptr(), stream)   # kernels on torch's current stream; returns when they are done
+        stats.append((s.samples, s.rays_closest, s.rays_shadow, s.segments, s.seconds_main_kernel, s.seconds_render))
+        return parallel.gather_film(local, H, W, rank, world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    film = None
+    for _ in range(args.warmup):
+        film = step()
+    stats.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        film = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    tot = torch.tensor([float(sum(s[0] for s in stats)), float(sum(s[1] + s[2] for s in stats))], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(tt.item())
+    total_samples, total_rays = float(tot[0].item()), float(tot[1].item())
+
+    if rank == 0:
+        assert film is not None and tuple(film.shape) == (H, W, 3)
+        assert total_samples == float(W) * H * spp * args.steps, "work was skipped inside the timed region"
+        mean_radiance = float(film.clamp(0, 1).mean().item())
+        # dominant kernel (rank 0's launches): algorithmic bytes / measured kernel time
+        n = len(stats)
+        seg = sum(s[3] for s in stats) / n
+        shd = sum(s[2] for s in stats) / n
+        smp = sum(s[0] for s in stats) / n
+        kern_s = sum(s[4] for s in stats) / n
+        alg_bytes = BYTES_PER_SEGMENT * seg + BYTES_PER_SHADOW_RAY * shd + BYTES_PER_SAMPLE * smp
+        achieved = alg_bytes / kern_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("workload") == [os.path.basename(args.scene), W, H, spp] and world == 1:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                pass
+        out = {
+            "metric": "Msamples/s (Cornell box, NEE+MIS path tracing; Mrays/s alongside)",
+            "value": total_samples / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (scene generated from the reference's cornell_box.json description; no image assets)",
+            "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H} {spp}spp max_depth={args.max_depth} NEE+MIS mnee=off",
+                       "parallelism": f"row-interleaved x{world}, film gather over RCCL" if world > 1 else "single GPU",
+                       "pipeline": {abi.PIPELINE_FUSED: "fused", abi.PIPELINE_WAVEFRONT: "wavefront"}.get(pt.last_stats.pipeline_used, "?"),
+                       "seed": 1234},
+            "mrays_per_s": total_rays / elapsed / 1e6,
+            "mrays_per_s_per_gpu": total_rays / elapsed / 1e6 / world,
+            "msamples_per_s_per_gpu": total_samples / elapsed / 1e6 / world,
+            "segments_per_sample": seg / smp,
+            "film_mean_clamped": mean_radiance,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic,
+                         "kernel": "render_fused_kernel<float>" if pt.last_stats.pipeline_used == abi.PIPELINE_FUSED else "wavefront iteration kernels",
+                         "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and args.cpu_baseline_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(pkg, sd, args)
+        print(json.dumps(out), flush=True)
+    pt.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pkg, sd, args):
+    """The CPU oracle (a restatement of the reference renderer, same estimator, fp64, OpenMP
+    over rows) timed on this host on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    osc = O.OracleScene(sd)
+    W, H = 320, 180
+    cam = sd.camera(W, H)
+    probe_spp = 4
+    _, ps = osc.render(cam, sd.settings(width=W, height=H, samples_per_pixel=probe_spp, max_depth=args.max_depth, seed=1), O.RNG_COUNTER, threads)
+    rate = W * H * probe_spp / max(ps.seconds_render, 1e-6)
+    spp = int(max(8, min(2048, args.cpu_baseline_seconds * rate / (W * H))))
+    _, s = osc.render(cam, sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=args.max_depth, seed=2), O.RNG_COUNTER, threads)
+    return {"value": s.samples / s.seconds_render / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"{os.path.basename(args.scene)} {W}x{H} {spp}spp max_depth={args.max_depth} NEE+MIS (same scene and estimator, reduced resolution), {s.seconds_render:.1f} s",
+            "mrays_per_s_reference_equivalent": (s.rays_closest + s.rays_shadow) / s.seconds_render / 1e6}
+
+
+if __name__ == "__main__":
+    main()

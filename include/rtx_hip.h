@@ -123,7 +123,8 @@ typedef struct rtx_stats {
   uint64_t rays_closest;     /* closest-hit queries executed */
   uint64_t rays_shadow;      /* shadow (any-hit) queries executed */
   uint64_t segments;         /* path vertices shaded */
-  double seconds_render;     /* device time of the render kernels (HIP events) */
+  double seconds_render;     /* device time of all render kernels of the call (HIP events) */
+  double seconds_main_kernel;/* device time of the dominant kernel alone (fused: the path-tracing kernel) */
   double seconds_total;      /* wall time of the call */
   uint32_t kernel_launches;
   uint32_t pipeline_used;    /* RTX_PIPELINE_FUSED or _WAVEFRONT */

@@ -13,6 +13,7 @@
 //   hits   <scene.json> <rays.bin> <out.bin> [tris.bin]
 //   render <scene.json> <W> <H> <spp> <depth> <seed> <nee> <mis> <mnee> <threads> <out.bin>
 //   kat    <scene.json> <seed> <n> <out.bin>
+//   texels <scene.json> <out_prefix>
 //
 // Reference entry points exercised: SceneLoader::load (engine/scene_loader.hpp:98),
 // Scene::hit (engine/scene.hpp:574), BVH::build/hit (engine/bvh.hpp:148,161),
@@ -339,6 +340,23 @@ int cmd_kat(const char* scene_path, unsigned seed, int n, const char* out) {
   return 0;
 }
 
+// Decoded 8-bit texels of every image texture, in material order: <prefix><material id>.rgb
+// preceded by two int32 (width, height).  Lets the repo pin its own image decoding.
+int cmd_texels(const char* scene_path, const char* prefix) {
+  auto d = SceneLoader::load(scene_path);
+  for (size_t i = 0; i < d.scene.materials.size(); ++i) {
+    const Texture& t = d.scene.materials[i].texture;
+    if (!d.scene.materials[i].has_texture || !t.image_data) continue;
+    std::string fn = std::string(prefix) + std::to_string(i) + ".rgb";
+    FILE* f = fopen(fn.c_str(), "wb");
+    int32_t hdr[2] = {t.image_width, t.image_height};
+    fwrite(hdr, 4, 2, f);
+    fwrite(t.image_data->data(), 1, t.image_data->size(), f);
+    fclose(f);
+  }
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -349,6 +367,7 @@ int main(int argc, char** argv) {
   if (cmd == "hits" && argc >= 5) return cmd_hits(argv[2], argv[3], argv[4], argc > 5 ? argv[5] : nullptr);
   if (cmd == "render") return cmd_render(argc, argv);
   if (cmd == "kat" && argc >= 6) return cmd_kat(argv[2], (unsigned)strtoul(argv[3], nullptr, 10), atoi(argv[4]), argv[5]);
+  if (cmd == "texels" && argc >= 4) return cmd_texels(argv[2], argv[3]);
   fprintf(stderr, "bad command\n");
   return 2;
 }

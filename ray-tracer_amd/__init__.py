@@ -3,4 +3,4 @@
 The directory name carries a hyphen, so import it through ``rtx_pkg.load()`` (repo root),
 which registers it as the module ``raytracer_amd``.
 """
-from . import abi, scene_loader, renderer  # noqa: F401
+from . import abi, scene_loader, renderer, synthetic  # noqa: F401  (parallel imports torch: import it explicitly)

@@ -13,7 +13,7 @@ namespace rtx {
 // ------------------------------------------------------------------------------------------
 bool DeviceBuffer::ensure(size_t bytes) {
   if (bytes <= cap && ptr) return true;
-  if (ptr) { hipFree(ptr); ptr = nullptr; cap = 0; }
+  if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
   if (bytes == 0) bytes = 16;
   if (hipMalloc(&ptr, bytes) != hipSuccess) { ptr = nullptr; return false; }
   cap = bytes;
@@ -25,7 +25,7 @@ bool DeviceBuffer::upload(const void* src, size_t bytes) {
   return hipMemcpy(ptr, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
 }
 void DeviceBuffer::release() {
-  if (ptr) hipFree(ptr);
+  if (ptr) (void)hipFree(ptr);
   ptr = nullptr; cap = 0;
 }
 void WavefrontPool::release() { state.release(); queues.release(); control.release(); }

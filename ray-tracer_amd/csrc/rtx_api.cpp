@@ -43,7 +43,7 @@ using namespace rtx;
 struct rtx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;
   int n_cus = 256;
   bool has_scene = false, has_camera = false;
   HostScene scene;          // device-resident copies + BVHs
@@ -73,7 +73,7 @@ int rtx_selftest(int device_id) {
   launch_selftest(d, n, nullptr);
   std::vector<float> h(n);
   hipError_t e = hipMemcpy(h.data(), d, n * sizeof(float), hipMemcpyDeviceToHost);
-  hipFree(d);
+  (void)hipFree(d);
   if (e != hipSuccess) return fail(RTX_ERR_HIP, "selftest copy: %s", hipGetErrorString(e));
   for (int i : {0, 1, 1023})
     if (std::fabs(h[i] - (float)i * 0.001f) > 1e-6f) return fail(RTX_ERR_HIP, "selftest: out[%d] = %g", i, h[i]);
@@ -91,7 +91,7 @@ int rtx_create(rtx_ctx** out_ctx, int device_id) {
   c->device = device_id;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount;
-  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->evm) != hipSuccess) {
     delete c;
     return fail(RTX_ERR_HIP, "stream/event creation failed");
   }
@@ -101,14 +101,15 @@ int rtx_create(rtx_ctx** out_ctx, int device_id) {
 
 int rtx_destroy(rtx_ctx* c) {
   if (!c) return RTX_OK;
-  hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
   c->scene.release();
   c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release();
   c->wf.release();
-  if (c->ev0) hipEventDestroy(c->ev0);
-  if (c->ev1) hipEventDestroy(c->ev1);
-  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->evm) (void)hipEventDestroy(c->evm);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return RTX_OK;
 }
@@ -203,9 +204,11 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     int grid = (int)std::min<unsigned long long>((items + kBlock - 1) / kBlock, (unsigned long long)c->n_cus * blocks_per_cu);
     if (f64) {
       launch_render_fused(c->scene.dev_d, c->cam_d, P, (double*)c->partial.ptr, (DCounters*)c->counters.ptr, grid, lds, stream);
+      HIP_TRY(hipEventRecord(c->evm, stream));
       launch_film_reduce((const double*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
     } else {
       launch_render_fused(c->scene.dev_f, c->cam_f, P, (float*)c->partial.ptr, (DCounters*)c->counters.ptr, grid, lds, stream);
+      HIP_TRY(hipEventRecord(c->evm, stream));
       launch_film_reduce((const float*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
     }
     st.kernel_launches = 2;
@@ -213,6 +216,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     std::string err;
     int rc = wavefront_render(c->wf, c->scene.dev_f, c->cam_f, P, d_film, (DCounters*)c->counters.ptr, c->n_cus, needs_stack, stream, st.kernel_launches, err);
     if (rc != RTX_OK) return fail(rc, "wavefront: %s", err.c_str());
+    HIP_TRY(hipEventRecord(c->evm, stream));
   }
   HIP_TRY(hipEventRecord(c->ev1, stream));
   HIP_TRY(hipGetLastError());
@@ -224,6 +228,8 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   st.samples = hc.samples; st.rays_closest = hc.closest; st.rays_shadow = hc.shadow; st.segments = hc.segments;
   st.seconds_render = ms * 1e-3;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->evm));
+  st.seconds_main_kernel = ms * 1e-3;
   st.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
   st.pipeline_used = (uint32_t)pipeline;
   if (stats) *stats = st;

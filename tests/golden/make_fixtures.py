@@ -1,0 +1,204 @@
+"""Regenerate tests/golden/ from the REAL reference renderer.
+
+Runs only where /root/reference exists (the build container): it drives
+oracle/_ref/ref_harness, i.e. the reference's own SceneLoader, Scene::hit, BVH::build and
+Renderer::render compiled in place by oracle/Makefile.  The outputs are data only:
+
+  loader/<scene>.json   tables SceneLoader::load produced (materials in id order, primitives,
+                        lights with derived members, Camera vectors, render settings)
+  hits/<scene>.npz      ray sets + Scene::hit results (t, primitive, material, normal, point, u, v)
+  bvh/<name>.npz        node / primitive arrays of the BVH exactly as Scene::build_bvh makes it
+  films/<name>.npz      seeded single-thread Renderer::render films (std::mt19937 seed given)
+  converged/<scene>.npz higher-sample films + the measured Monte-Carlo noise floor
+  kat/<scene>.npy       scalar known-answer stream (light sampling, pdfs, env lookup, textures, ...)
+
+Usage:  python tests/golden/make_fixtures.py
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import rtx_pkg  # noqa: E402
+
+pkg = rtx_pkg.load()
+REF = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+REFROOT = "/root/reference"
+SCENES = os.path.join(HERE, "scenes")
+
+HIT_DTYPE = pkg.renderer.HIT_DTYPE
+
+
+def run(args, **kw):
+    # cwd = tests/golden so that "textures/..." inside scene files resolves against the copies
+    # of the reference's assets kept there (the reference resolves them against its cwd)
+    return subprocess.run([REF] + [str(a) for a in args], cwd=HERE, check=True, capture_output=True, text=True, **kw)
+
+
+def scene_path(name):
+    return os.path.join(SCENES, name + ".json")
+
+
+def dump_loader(name):
+    out = run(["dump", scene_path(name)]).stdout
+    line = [l for l in out.splitlines() if l.startswith("@@JSON@@")][-1][len("@@JSON@@"):]
+    doc = json.loads(line)
+    os.makedirs(os.path.join(HERE, "loader"), exist_ok=True)
+    with open(os.path.join(HERE, "loader", name + ".json"), "w") as f:
+        json.dump(doc, f, indent=0, separators=(",", ":"))
+        f.write("\n")
+    return doc
+
+
+def camera_rays(doc, W, H):
+    cam = doc["camera"]
+    # Camera vectors were computed for the scene's own aspect; rebuild for W x H the way the
+    # test does (through the package's Camera mirror, itself pinned by loader/<scene>.json).
+    c = pkg.scene_loader.make_camera(tuple(cam["position"]), tuple(cam["target"]), tuple(cam["up"]), cam["fov"], float(W) / H)
+    o = np.array(c.origin[:]); llc = np.array(c.lower_left_corner[:]); hz = np.array(c.horizontal[:]); vt = np.array(c.vertical[:])
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+    s = ((xs + 0.5) / W).ravel(); t = ((ys + 0.5) / H).ravel()
+    d = ((llc[None] + s[:, None] * hz[None]) + t[:, None] * vt[None]) - o[None]
+    n = W * H
+    return np.concatenate([np.tile(o, (n, 1)), d, np.full((n, 1), 0.001), np.full((n, 1), 1e9)], axis=1)
+
+
+def random_rays(n, seed, centre, half):
+    rng = np.random.default_rng(seed)
+    ro = rng.uniform(-1, 1, (n, 3)) * np.asarray(half) + np.asarray(centre)
+    rd = rng.normal(size=(n, 3))
+    k = n // 10
+    rd[0 * k:1 * k, 0] = 0.0           # zero components: the 1/0 slab paths
+    rd[1 * k:2 * k, 1] = 0.0
+    rd[2 * k:3 * k, 2] = -0.0
+    rd[3 * k:4 * k, 1:] = 0.0          # axis-parallel rays
+    rd[4 * k:5 * k] *= 1e-3            # short, unnormalised directions
+    tmax = rng.choice([1e9, 4.0, 0.75], (n, 1))
+    tmin = rng.choice([0.001, 0.0, 0.25], (n, 1))
+    return np.concatenate([ro, rd, tmin, tmax], axis=1)
+
+
+def ref_hits(name, rays, tris=None):
+    with tempfile.TemporaryDirectory() as td:
+        rp, op = os.path.join(td, "rays.bin"), os.path.join(td, "hits.bin")
+        np.ascontiguousarray(rays, dtype=np.float64).tofile(rp)
+        args = ["hits", scene_path(name), rp, op]
+        if tris is not None:
+            tp = os.path.join(td, "tris.bin")
+            tris_to_bin(tris).tofile(tp)
+            args.append(tp)
+        run(args)
+        return np.fromfile(op, dtype=HIT_DTYPE)
+
+
+def tris_to_bin(tri):
+    out = np.zeros((tri.shape[0], 10), dtype=np.float64)
+    out[:, 0:3] = tri["v0"]; out[:, 3:6] = tri["v1"]; out[:, 6:9] = tri["v2"]; out[:, 9] = tri["material_id"]
+    return out
+
+
+def ref_bvh(name, tris=None):
+    with tempfile.TemporaryDirectory() as td:
+        op = os.path.join(td, "bvh.bin")
+        args = ["bvh", scene_path(name), op]
+        if tris is not None:
+            tp = os.path.join(td, "tris.bin")
+            tris_to_bin(tris).tofile(tp)
+            args.append(tp)
+        run(args)
+        raw = open(op, "rb").read()
+    nn, npr = np.frombuffer(raw[:16], dtype=np.int64)
+    node_dt = np.dtype([("box", "<f8", 6), ("ints", "<i4", 4)])
+    nodes = np.frombuffer(raw[16:16 + nn * node_dt.itemsize], dtype=node_dt)
+    prims = np.frombuffer(raw[16 + nn * node_dt.itemsize:], dtype=np.int32).reshape(npr, 2)
+    return nodes["box"].copy(), nodes["ints"].copy(), prims.copy()
+
+
+def ref_film(name, W, H, spp, depth, seed, nee=1, mis=1, mnee=0, threads=1):
+    with tempfile.TemporaryDirectory() as td:
+        op = os.path.join(td, "film.bin")
+        out = run(["render", scene_path(name), W, H, spp, depth, seed, nee, mis, mnee, threads, op]).stdout
+        raw = np.fromfile(op, dtype=np.uint8)
+    secs = float([l for l in out.splitlines() if l.startswith("@@TIME@@")][-1].split()[1])
+    return np.frombuffer(raw[8:].tobytes(), dtype=np.float64).reshape(H, W, 3).copy(), secs
+
+
+def rel_mse(x, r):
+    x = np.clip(x, 0.0, 1.0); r = np.clip(r, 0.0, 1.0)   # the film Renderer::render returns is clamped
+    return float(np.mean((x - r) ** 2 / (r ** 2 + 1e-2)))
+
+
+def main():
+    if not os.path.exists(REF):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    for sub in ("loader", "hits", "bvh", "films", "converged", "kat"):
+        os.makedirs(os.path.join(HERE, sub), exist_ok=True)
+
+    names = ["cornell_box", "cornell_box_quad", "caustics_test", "environment_demo", "earth_demo", "demo", "kitchen_sink", "textured", "disk_room"]
+    docs = {n: dump_loader(n) for n in names}
+    print("loader dumps:", len(docs))
+
+    # --- closest hits -------------------------------------------------------------------
+    boxes = {"cornell_box": ((0, 2.5, -2.0), (2.4, 2.4, 3.5)), "cornell_box_quad": ((0, 2.5, -2.0), (2.4, 2.4, 3.5)),
+             "environment_demo": ((0, 0.5, 1.0), (4, 2, 4)), "demo": ((0, 1, 0), (4, 2, 4)), "kitchen_sink": ((0, 1.5, -2), (4, 2, 4)), "textured": ((0, 1.5, -2), (4, 2, 4)), "disk_room": ((0, 1.5, -1.5), (3, 1.5, 3))}
+    for n, (c, h) in boxes.items():
+        rays = np.concatenate([camera_rays(docs[n], 48, 27), random_rays(3000, 17, c, h)], axis=0)
+        hits = ref_hits(n, rays)
+        np.savez_compressed(os.path.join(HERE, "hits", n + ".npz"), rays=rays, hits=hits)
+        print("hits", n, len(rays), int(hits["hit"].sum()))
+    # triangle soup appended to the quad-light Cornell box: exercises the tree walk
+    soup = pkg.synthetic.triangle_soup(4000, seed=7, extent=2.2, size=0.25, n_materials=5)
+    soup["v0"] += (0, 2.5, -2.5); soup["v1"] += (0, 2.5, -2.5); soup["v2"] += (0, 2.5, -2.5)
+    rays = np.concatenate([camera_rays(docs["cornell_box_quad"], 64, 64), random_rays(6000, 23, (0, 2.5, -2.5), (2.4, 2.4, 2.4))], axis=0)
+    hits = ref_hits("cornell_box_quad", rays, soup)
+    np.savez_compressed(os.path.join(HERE, "hits", "soup.npz"), rays=rays, hits=hits, soup_n=4000, soup_seed=7)
+    b, ii, pr = ref_bvh("cornell_box_quad", soup)
+    np.savez_compressed(os.path.join(HERE, "bvh", "soup.npz"), boxes=b, ints=ii, prims=pr)
+    b, ii, pr = ref_bvh("kitchen_sink")
+    np.savez_compressed(os.path.join(HERE, "bvh", "kitchen_sink.npz"), boxes=b, ints=ii, prims=pr)
+    print("soup hits", int(hits["hit"].sum()), "bvh nodes", len(ii))
+
+    # --- seeded single-thread films (bit-reproducible) ----------------------------------
+    films = [("cornell_box", 32, 18, 4, 500, 77, 1, 1), ("cornell_box", 24, 14, 4, 40, 78, 1, 0), ("cornell_box", 24, 14, 4, 40, 79, 0, 0),
+             ("cornell_box_quad", 24, 24, 4, 50, 80, 1, 1), ("caustics_test", 24, 24, 4, 16, 81, 1, 1),
+             ("environment_demo", 32, 18, 4, 50, 82, 1, 1), ("environment_demo", 24, 14, 3, 50, 85, 1, 0),
+             ("demo", 32, 18, 4, 50, 84, 1, 1),
+             ("textured", 32, 18, 4, 12, 89, 1, 1), ("kitchen_sink", 40, 24, 6, 24, 86, 1, 1), ("kitchen_sink", 24, 14, 4, 24, 87, 1, 0), ("kitchen_sink", 24, 14, 4, 24, 88, 0, 1),
+             # disk lights: with NEE and MIS both on the reference indexes materials[-1000] in its look-ahead
+             # (engine/renderer.cpp:803) and crashes, so its disk-light behaviour can only be pinned with one of them off
+             ("disk_room", 32, 18, 6, 12, 90, 1, 0), ("disk_room", 24, 14, 4, 12, 91, 0, 1)]
+    for (n, W, H, spp, depth, seed, nee, mis) in films:
+        film, _ = ref_film(n, W, H, spp, depth, seed, nee, mis)
+        tag = f"{n}_{W}x{H}_s{spp}_d{depth}_seed{seed}_nee{nee}_mis{mis}"
+        np.savez_compressed(os.path.join(HERE, "films", tag + ".npz"), film=film, scene=n, W=W, H=H, spp=spp, depth=depth, seed=seed, nee=nee, mis=mis)
+        print("film", tag, float(film.mean()))
+
+    # --- converged references + noise floor ----------------------------------------------
+    for n, depth in (("cornell_box", 500), ("cornell_box_quad", 50), ("caustics_test", 16), ("environment_demo", 50), ("kitchen_sink", 24)):
+        W, H, N = 64, 36, 256
+        hi, secs = ref_film(n, W, H, 4 * N, depth, 1001, threads=8)
+        lo_a, _ = ref_film(n, W, H, N, depth, 2002, threads=8)
+        lo_b, _ = ref_film(n, W, H, N, depth, 3003, threads=8)
+        floor = max(rel_mse(lo_a, hi), rel_mse(lo_b, hi))
+        np.savez_compressed(os.path.join(HERE, "converged", n + ".npz"), film=hi.astype(np.float32), W=W, H=H, N=N, depth=depth,
+                            noise_floor_relmse=floor, mean_lo_a=lo_a.mean(axis=(0, 1)), mean_lo_b=lo_b.mean(axis=(0, 1)),
+                            ref_msamples_per_s_8threads=W * H * 4 * N / secs * 1e-6)
+        print("converged", n, "floor", floor, "ref Msamples/s", W * H * 4 * N / secs * 1e-6)
+
+    # --- scalar known answers ---------------------------------------------------------------
+    for n in ("kitchen_sink", "environment_demo", "cornell_box", "textured", "disk_room"):
+        with tempfile.TemporaryDirectory() as td:
+            op = os.path.join(td, "kat.bin")
+            run(["kat", scene_path(n), 4242, 48, op])
+            np.save(os.path.join(HERE, "kat", n + ".npy"), np.fromfile(op, dtype=np.float64))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,190 @@
+"""The CPU oracle (oracle/pt_oracle.cpp) and the host-side loader mirror against fixtures the
+REAL reference produced (tests/golden/make_fixtures.py).  Integer and bit-level equality
+throughout: the oracle is only trusted because it reproduces the reference exactly."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_mse, soup_scene
+
+SCENES = ["cornell_box", "cornell_box_quad", "caustics_test", "environment_demo", "earth_demo", "demo", "kitchen_sink", "textured", "disk_room"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def v3(x):
+    return [float(x[0]), float(x[1]), float(x[2])]
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_loader_tables_equal_reference_loader(name, pkg, load_scene):
+    """SceneLoader::load (engine/scene_loader.hpp:98-472): every double identical."""
+    doc = json.load(open(os.path.join(GOLDEN, "loader", name + ".json")))
+    sd = load_scene(name)
+    assert len(sd.materials) == len(doc["materials"])
+    for m, e in zip(sd.materials, doc["materials"]):
+        assert m.type == e["type"] and v3(m.albedo) == e["albedo"] and v3(m.emission) == e["emission"]
+        assert m.fuzz == e["fuzz"] and m.refraction_index == e["ior"] and m.has_texture == e["has_texture"]
+        if m.has_texture:
+            assert m.tex_type == e["tex_type"] and v3(m.tex_color1) == e["tex_c1"] and v3(m.tex_color2) == e["tex_c2"] and m.tex_scale == e["tex_scale"]
+            if m.tex_type == pkg.abi.TEX_IMAGE:
+                img = sd.images[m.tex_image]
+                assert (img.shape[1], img.shape[0]) == (e["tex_w"], e["tex_h"])
+    assert [(v3(s.center), s.radius, s.material_id) for s in sd.spheres] == [(e["center"], e["radius"], e["material"]) for e in doc["spheres"]]
+    assert [(v3(p.point), v3(p.normal), p.material_id) for p in sd.planes] == [(e["point"], e["normal"], e["material"]) for e in doc["planes"]]
+    assert [(v3(b.box_min), v3(b.box_max), b.material_id) for b in sd.boxes] == [(e["min"], e["max"], e["material"]) for e in doc["boxes"]]
+    assert [(v3(t.v0), v3(t.v1), v3(t.v2), t.material_id) for t in sd.triangles] == [(e["v0"], e["v1"], e["v2"], e["material"]) for e in doc["triangles"]]
+    assert [(v3(l.position), v3(l.intensity)) for l in sd.point_lights] == [(e["position"], e["intensity"]) for e in doc["point_lights"]]
+    assert [(v3(q.corner), v3(q.edge_u), v3(q.edge_v), v3(q.normal), v3(q.emission), q.area) for q in sd.quad_lights] == \
+        [(e["corner"], e["edge_u"], e["edge_v"], e["normal"], e["emission"], e["area"]) for e in doc["quad_lights"]]
+    assert [(v3(q.center), v3(q.normal), q.radius, v3(q.emission), q.area, v3(q.tangent), v3(q.bitangent)) for q in sd.disk_lights] == \
+        [(e["center"], e["normal"], e["radius"], e["emission"], e["area"], e["tangent"], e["bitangent"]) for e in doc["disk_lights"]]
+    cam = sd.camera()
+    c = doc["camera"]
+    assert v3(cam.origin) == c["origin"] and v3(cam.lower_left_corner) == c["lower_left_corner"]
+    assert v3(cam.horizontal) == c["horizontal"] and v3(cam.vertical) == c["vertical"]
+    r = doc["render"]
+    assert (sd.width, sd.height, sd.samples, sd.max_depth, sd.mode, int(sd.use_nee), int(sd.use_mis), sd.tone_mapper, sd.exposure, sd.output_file) == \
+        (r["width"], r["height"], r["samples"], r["max_depth"], r["mode"], r["nee"], r["mis"], r["tone_mapper"], r["exposure"], r["output"])
+    b = doc["background"]
+    assert (list(sd.background_color), list(sd.background_top), list(sd.background_bottom), int(sd.use_background_gradient)) == (b["color"], b["top"], b["bottom"], b["gradient"])
+    if "environment" in doc:
+        e = doc["environment"]
+        assert sd.env_texels.shape == (e["height"], e["width"], 3) and sd.env_intensity == e["intensity"] and sd.env_rotation == e["rotation"]
+    else:
+        assert sd.env_texels is None
+
+
+def test_material_ids_are_alphabetical(load_scene):
+    sd = load_scene("cornell_box")
+    assert sd.material_names == ["glass", "green", "light", "metal", "red", "white"]
+
+
+def test_unknown_material_falls_back_to_zero_and_position_only_keys(load_scene):
+    ks = load_scene("kitchen_sink")
+    assert ks.spheres[-1].material_id == 0                      # "no_such_material"
+    ed = load_scene("earth_demo")                                 # uses center/point keys the loader ignores
+    assert [v3(s.center) for s in ed.spheres] == [[0.0, 0.0, 0.0]] * 2 and v3(ed.planes[0].point) == [0.0, 0.0, 0.0]
+
+
+def test_env_tables_and_lookup_match_reference(oracle, load_scene):
+    """total luminance is printed by the reference loader; lookups are pinned by the kat stream."""
+    doc = json.load(open(os.path.join(GOLDEN, "loader", "environment_demo.json")))
+    sd = load_scene("environment_demo")
+    t = sd.env_texels.astype(np.float64)
+    h = t.shape[0]
+    st = np.sin(np.pi * (np.arange(h) + 0.5) / h)
+    total = ((0.2126 * t[..., 0] + 0.7152 * t[..., 1] + 0.0722 * t[..., 2]) * st[:, None]).sum()
+    assert abs(total - doc["environment"]["total_luminance"]) / total < 1e-12
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "demo", "kitchen_sink", "textured", "disk_room"])
+def test_closest_hit_bit_exact(name, oracle, load_scene):
+    """Scene::hit (engine/scene.hpp:574-674): winner, t, point, normal, u, v — all bits."""
+    fx = np.load(os.path.join(GOLDEN, "hits", name + ".npz"))
+    got = oracle.OracleScene(load_scene(name)).trace_closest(fx["rays"], threads=4)
+    exp = fx["hits"]
+    for f in ("hit", "prim_type", "prim_index", "material_id", "front_face"):
+        assert np.array_equal(got[f], exp[f]), f
+    for f in ("t", "point", "normal", "u", "v"):
+        assert np.array_equal(bits(got[f]), bits(exp[f])), f
+
+
+def test_closest_hit_triangle_soup_bit_exact(pkg, oracle, load_scene):
+    fx = np.load(os.path.join(GOLDEN, "hits", "soup.npz"))
+    osc = oracle.OracleScene(soup_scene(pkg, load_scene))
+    got = osc.trace_closest(fx["rays"], threads=4)
+    exp = fx["hits"]
+    assert exp["hit"].sum() > 5000 and (exp["prim_type"] == 2).sum() > 2000
+    for f in ("hit", "prim_type", "prim_index", "material_id", "front_face"):
+        assert np.array_equal(got[f], exp[f]), f
+    for f in ("t", "point", "normal", "u", "v"):
+        assert np.array_equal(bits(got[f]), bits(exp[f])), f
+
+
+@pytest.mark.parametrize("name", ["soup", "kitchen_sink"])
+def test_bvh_identical_to_reference_build(name, pkg, oracle, load_scene):
+    """BVH::build (engine/bvh.hpp:148-218): node boxes, topology and primitive permutation."""
+    fx = np.load(os.path.join(GOLDEN, "bvh", name + ".npz"))
+    sd = soup_scene(pkg, load_scene) if name == "soup" else load_scene(name)
+    boxes, ints, prims = oracle.OracleScene(sd).bvh()
+    assert np.array_equal(ints, fx["ints"]) and np.array_equal(prims, fx["prims"])
+    assert np.array_equal(bits(boxes), bits(fx["boxes"]))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "films", "*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
+def test_seeded_film_bit_exact(path, oracle, load_scene):
+    """Renderer::render + ray_color_path (engine/renderer.cpp:378-449, :580-841), use_mnee off:
+    same std::mt19937 seed, one thread => the same film, every bit."""
+    fx = np.load(path)
+    sd = load_scene(str(fx["scene"]))
+    W, H = int(fx["W"]), int(fx["H"])
+    st = sd.settings(width=W, height=H, samples_per_pixel=int(fx["spp"]), max_depth=int(fx["depth"]), seed=int(fx["seed"]),
+                     use_nee=int(fx["nee"]), use_mis=int(fx["mis"]))
+    film, _ = oracle.OracleScene(sd).render(sd.camera(W, H), st, oracle.RNG_MT19937, threads=1)
+    if len(sd.quad_lights) and int(fx["nee"]) and int(fx["mis"]):
+        # When a BSDF ray lands on a quad light the reference's look-ahead reads materials[-1]
+        # (engine/renderer.cpp:803, undefined behaviour): whatever lies before its material array
+        # is taken as an "emission".  In this build of it that garbage is denormal-sized and moves
+        # a handful of film values by one unit in the last place; the oracle defines the read as
+        # "not emissive".  Everything else must still be identical.
+        diff = bits(film) != bits(fx["film"])
+        assert diff.mean() < 2e-3 and np.abs(film - fx["film"]).max() < 1e-15
+    else:
+        assert np.array_equal(bits(film), bits(fx["film"]))
+
+
+@pytest.mark.parametrize("name", ["kitchen_sink", "environment_demo", "cornell_box", "textured", "disk_room"])
+def test_scalar_known_answers(name, oracle, load_scene):
+    """sample_light / light_pdf / env_light_pdf / EnvironmentMap::sample / get_albedo /
+    reflectance / vec3_refract / vec3_reflect on inputs drawn from the reference's generator."""
+    exp = np.load(os.path.join(GOLDEN, "kat", name + ".npy"))
+    got = oracle.OracleScene(load_scene(name)).kat(4242, 48)
+    assert got.shape == exp.shape
+    assert np.array_equal(bits(got), bits(exp))
+
+
+def test_philox_known_answers(oracle):
+    """Random123 kat_vectors for philox4x32-10."""
+    assert [hex(v) for v in oracle.philox([0, 0, 0, 0], [0, 0])] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(v) for v in oracle.philox([0xffffffff] * 4, [0xffffffff] * 2)] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    assert [hex(v) for v in oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])] == \
+        ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_counter_mode_is_thread_and_shard_invariant(oracle, load_scene):
+    sd = load_scene("cornell_box_quad")
+    W, H = 20, 12
+    cam = sd.camera(W, H)
+    osc = oracle.OracleScene(sd)
+    full, st = osc.render(cam, sd.settings(width=W, height=H, samples_per_pixel=3, max_depth=8), oracle.RNG_COUNTER, threads=1)
+    again, _ = osc.render(cam, sd.settings(width=W, height=H, samples_per_pixel=3, max_depth=8), oracle.RNG_COUNTER, threads=4)
+    assert np.array_equal(bits(full), bits(again)) and st.samples == W * H * 3
+    acc = np.zeros_like(full)
+    for k in range(3):
+        part, _ = osc.render(cam, sd.settings(width=W, height=H, samples_per_pixel=3, max_depth=8, shard_index=k, shard_count=3), oracle.RNG_COUNTER, threads=2)
+        assert np.all(part[[y for y in range(H) if y % 3 != k]] == 0)
+        acc += part
+    assert np.array_equal(bits(acc), bits(full))
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "caustics_test", "environment_demo"])
+def test_counter_mode_estimator_matches_reference_statistically(name, oracle, load_scene):
+    """The counter-based sampler changes the random numbers, not the estimator: at N spp its
+    relMSE against the reference's 4N-spp film stays within 1.25x the reference's own
+    seed-to-seed noise floor, and channel means agree within 1.5 % (seed-to-seed spread of the
+    reference at this size is 0.3-0.6 %)."""
+    fx = np.load(os.path.join(GOLDEN, "converged", name + ".npz"))
+    sd = load_scene(name)
+    W, H, N = int(fx["W"]), int(fx["H"]), int(fx["N"])
+    film, _ = oracle.OracleScene(sd).render(sd.camera(W, H), sd.settings(width=W, height=H, samples_per_pixel=N, max_depth=int(fx["depth"]), seed=99),
+                                            oracle.RNG_COUNTER, threads=8)
+    ref = fx["film"].astype(np.float64)
+    assert rel_mse(film, ref) <= 1.25 * float(fx["noise_floor_relmse"])
+    mg, mr = np.clip(film, 0, 1).mean(axis=(0, 1)), np.clip(ref, 0, 1).mean(axis=(0, 1))
+    assert np.all(np.abs(mg - mr) / mr < 0.015), (mg, mr)
