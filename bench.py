@@ -159,11 +159,32 @@ def main():
 
 
 def cpu_baseline(pkg, sd, args):
-    """The CPU oracle (a restatement of the reference renderer, same estimator, fp64, OpenMP
-    over rows) timed on this host on a bounded sample of the same workload."""
+    """CPU renderer timed on this host's cores on a bounded sample of the same workload:
+    the REAL reference (oracle/_ref/ref_harness = its Renderer::render compiled in place, with
+    use_mnee = false) when that binary is present, else the CPU oracle (a restatement of it)."""
+    import re
+    import subprocess
+    import tempfile
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if os.path.exists(ref):
+        W, H = 320, 180
+
+        def run(spp):
+            with tempfile.TemporaryDirectory() as td:
+                o = subprocess.run([ref, "render", args.scene, str(W), str(H), str(spp), str(args.max_depth), "1", "1", "1", "0", str(threads),
+                                    os.path.join(td, "f.bin")], cwd=os.path.join(ROOT, "tests", "golden"), capture_output=True, text=True, check=True).stdout
+            return float(re.search(r"@@TIME@@ ([0-9.]+) s", o).group(1))
+        try:
+            t = run(4)
+            spp = int(max(8, min(4096, args.cpu_baseline_seconds / max(t, 1e-3) * 4)))
+            secs = run(spp)
+            return {"value": W * H * spp / secs / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "reference",
+                    "sample": f"reference Renderer::render (use_mnee=false) on {os.path.basename(args.scene)} {W}x{H} {spp}spp max_depth={args.max_depth} NEE+MIS, {secs:.1f} s"}
+        except (subprocess.CalledProcessError, OSError, AttributeError) as e:
+            print(f"reference baseline failed ({e}); falling back to the port", file=sys.stderr)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     osc = O.OracleScene(sd)
     W, H = 320, 180
     cam = sd.camera(W, H)

@@ -565,31 +565,34 @@ struct MtSampler {
 };
 
 // Sampler B: counter-based, identical to the GPU's.  key = (pixel index, seed);
-// counter = (sample index, block, 0, 0).  Block 0 holds the pixel jitter; bounce b uses
-// block 1+2b = {light select, light u, light v, roulette} and block 2+2b = {scatter u1,
-// scatter u2, fresnel, -}.  A uniform is the top 24 bits of a word times 2^-24, exactly
-// representable in float and double alike.
+// counter = (sample index, block, 0, 0).  Block 0 holds the pixel jitter (top 24 bits of words
+// 0 and 1, times 2^-24).  Path vertex b draws one block, 1+b, cut into 16-bit fields:
+// word0 = light u | light v, word1 = scatter u1 | scatter u2, word2 = light select | roulette,
+// word3 = fresnel | spare; a field k maps to (k + 0.5) / 65536.
 struct CounterSampler {
   uint32_t key[2]{0, 0}, sample = 0;
-  uint32_t a[4], b[4];
+  uint32_t w[4];
   int bounce = -1;
-  bool have_a = false, have_b = false;
-  void block(uint32_t blk, uint32_t out[4]) { uint32_t c[4] = {sample, blk, 0, 0}; philox4x32_10(c, key, out); }
-  void begin_sample(uint32_t pixel, uint32_t seed, uint32_t s) { key[0] = pixel; key[1] = seed; sample = s; bounce = -1; have_a = false; }
-  void begin_bounce(int bn) { bounce = bn; have_a = have_b = false; }
-  uint32_t* A() { if (!have_a) { block(bounce < 0 ? 0u : 1u + 2u * (uint32_t)bounce, a); have_a = true; } return a; }
-  uint32_t* B() { if (!have_b) { block(2u + 2u * (uint32_t)bounce, b); have_b = true; } return b; }
-  double jitter_x() { return u24(A()[0]); }
-  double jitter_y() { return u24(A()[1]); }
-  double light_select() { return u24(A()[0]); }
-  double light_u() { return u24(A()[1]); }
-  double light_v() { return u24(A()[2]); }
-  double roulette() { return u24(A()[3]); }
-  double fresnel() { return u24(B()[2]); }
+  bool have = false;
+  static double hi(uint32_t x) { return ((double)(x >> 16) + 0.5) * (1.0 / 65536.0); }
+  static double lo(uint32_t x) { return ((double)(x & 0xffffu) + 0.5) * (1.0 / 65536.0); }
+  void begin_sample(uint32_t pixel, uint32_t seed, uint32_t s) { key[0] = pixel; key[1] = seed; sample = s; bounce = -1; have = false; }
+  void begin_bounce(int bn) { bounce = bn; have = false; }
+  uint32_t* W() {
+    if (!have) { uint32_t c[4] = {sample, bounce < 0 ? 0u : 1u + (uint32_t)bounce, 0, 0}; philox4x32_10(c, key, w); have = true; }
+    return w;
+  }
+  double jitter_x() { return u24(W()[0]); }
+  double jitter_y() { return u24(W()[1]); }
+  double light_u() { return hi(W()[0]); }
+  double light_v() { return lo(W()[0]); }
+  double light_select() { return hi(W()[2]); }
+  double roulette() { return lo(W()[2]); }
+  double fresnel() { return hi(W()[3]); }
   V3 unit_vector() {  // uniform on the sphere: same law as the normalised rejection sample
-    double z = 1.0 - 2.0 * u24(B()[0]);
+    double z = 1.0 - 2.0 * hi(W()[1]);
     double r = std::sqrt(std::fmax(0.0, 1.0 - z * z));
-    double phi = 2.0 * kPi * u24(B()[1]);
+    double phi = 2.0 * kPi * lo(W()[1]);
     return {r * std::cos(phi), r * std::sin(phi), z};
   }
 };

@@ -18,7 +18,7 @@ extern "C" {
 typedef struct orc_scene orc_scene;
 
 enum { ORC_RNG_MT19937 = 0,  /* std::mt19937 drawn in the reference's order (engine/renderer.cpp:33-56) */
-       ORC_RNG_COUNTER = 1   /* Philox-4x32-10 keyed by (pixel, seed), the generator the GPU uses */ };
+       ORC_RNG_COUNTER = 1   /* Philox-4x32-10 keyed by (pixel, seed): one block per path vertex, the generator the GPU uses */ };
 
 int  orc_create(const rtx_scene_desc* desc, orc_scene** out);
 void orc_destroy(orc_scene* s);

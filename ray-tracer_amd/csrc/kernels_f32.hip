@@ -14,9 +14,20 @@ void launch_selftest(float* out, int n, hipStream_t stream) {
   hipLaunchKernelGGL(selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n);
 }
 
-void launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
-                         int grid, size_t lds_bytes, hipStream_t stream) {
-  hipLaunchKernelGGL(render_fused_kernel<float>, dim3(grid), dim3(kBlock), lds_bytes, stream, sc, cam, P, partial, counters);
+int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
+                        const FusedLaunch& L, hipStream_t stream) {
+  dim3 g(L.grid), b(kBlock);
+  if (L.mode == MODE_FLAT && L.lds_mats)
+    hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+  else if (L.mode == MODE_TREE && L.lds_mats)
+    hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+  else if (L.mode == MODE_TREE_UV && L.lds_mats)
+    hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+  else if (!L.lds_mats && L.mode != MODE_FLAT)
+    hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, false>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+  else
+    return -1;
+  return 0;
 }
 
 void launch_film_reduce(const float* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream) {
@@ -24,10 +35,14 @@ void launch_film_reduce(const float* partial, float* film, unsigned long long np
   hipLaunchKernelGGL(film_reduce_kernel<float>, dim3(grid), dim3(256), 0, stream, partial, film, npix, n_chunks, spp);
 }
 
-void launch_trace_fast(const DScene<float>& sc, const double* rays8, unsigned long long n, DHitOut* out, size_t lds_bytes, hipStream_t stream) {
-  if (n == 0) return;
+int launch_trace_fast(const DScene<float>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream) {
+  if (n == 0) return 0;
   unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(trace_fast_kernel<float>, dim3(grid), dim3(kBlock), lds_bytes, stream, sc, rays8, n, out);
+  if (mode == MODE_FLAT)
+    hipLaunchKernelGGL((trace_fast_kernel<float, MODE_FLAT>), dim3(grid), dim3(kBlock), lds_bytes, stream, sc, rays8, n, out);
+  else
+    hipLaunchKernelGGL((trace_fast_kernel<float, MODE_TREE_UV>), dim3(grid), dim3(kBlock), lds_bytes, stream, sc, rays8, n, out);
+  return 0;
 }
 
 }  // namespace rtx

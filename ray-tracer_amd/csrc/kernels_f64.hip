@@ -60,9 +60,18 @@ void launch_trace_ref(const DScene<double>& sc, const DSceneRef& ref, const doub
   hipLaunchKernelGGL(trace_ref_kernel, dim3(grid), dim3(64), 0, stream, sc, ref, rays8, n, out);
 }
 
-void launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters,
-                         int grid, size_t lds_bytes, hipStream_t stream) {
-  hipLaunchKernelGGL(render_fused_kernel<double>, dim3(grid), dim3(kBlock), lds_bytes, stream, sc, cam, P, partial, counters);
+int launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters,
+                        const FusedLaunch& L, hipStream_t stream) {
+  dim3 g(L.grid), b(kBlock);
+  if (L.mode == MODE_TREE && L.lds_mats)
+    hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+  else if (L.mode == MODE_TREE_UV && L.lds_mats)
+    hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+  else if (!L.lds_mats && L.mode != MODE_FLAT)
+    hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, false>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+  else
+    return -1;
+  return 0;
 }
 
 void launch_film_reduce(const double* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream) {
@@ -70,10 +79,12 @@ void launch_film_reduce(const double* partial, float* film, unsigned long long n
   hipLaunchKernelGGL(film_reduce_kernel<double>, dim3(grid), dim3(256), 0, stream, partial, film, npix, n_chunks, spp);
 }
 
-void launch_trace_fast(const DScene<double>& sc, const double* rays8, unsigned long long n, DHitOut* out, size_t lds_bytes, hipStream_t stream) {
-  if (n == 0) return;
+int launch_trace_fast(const DScene<double>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream) {
+  if (n == 0) return 0;
+  if (mode == MODE_FLAT) return -1;
   unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(trace_fast_kernel<double>, dim3(grid), dim3(kBlock), lds_bytes, stream, sc, rays8, n, out);
+  hipLaunchKernelGGL((trace_fast_kernel<double, MODE_TREE_UV>), dim3(grid), dim3(kBlock), lds_bytes, stream, sc, rays8, n, out);
+  return 0;
 }
 
 }  // namespace rtx

@@ -402,16 +402,22 @@ template <class R> RTX_DEV bool occluded(const DScene<R>& sc, const Ray<R>& r, R
 }
 
 // ------------------------------------------------------------------------------------------
-// counter-based random numbers: Philox-4x32-10, key = (pixel, seed), counter = (sample, block)
-// block 0: pixel jitter; bounce b: block 1+2b = {light select, light u, light v, roulette},
-// block 2+2b = {scatter u1, scatter u2, fresnel, -}.  A uniform is the top 24 bits of a word
-// times 2^-24: exactly representable in float and double, so both precisions see equal numbers.
+// counter-based random numbers: Philox-4x32-10, key = (pixel, seed), counter = (sample, block).
+// Block 0 holds the pixel jitter (top 24 bits of words 0 and 1).  Path vertex b draws ONE block,
+// 1+b, cut into 16-bit fields:  word0 = light u | light v,  word1 = scatter u1 | scatter u2,
+// word2 = light select | roulette,  word3 = fresnel | spare.  A field k maps to (k + 0.5) / 65536,
+// exactly representable in float and double, so both precisions see equal numbers.  (32-bit
+// integer multiplies are quarter-rate on CDNA: one block per vertex instead of two is worth
+// about a tenth of the whole kernel.)
 // ------------------------------------------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
 RTX_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1) {
   uint32_t c2 = 0, c3 = 0;
+#ifndef RTX_PHILOX_ROUNDS
+#define RTX_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-  for (int i = 0; i < 10; ++i) {
+  for (int i = 0; i < RTX_PHILOX_ROUNDS; ++i) {
     uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
     uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
     uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
@@ -421,6 +427,8 @@ RTX_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1) {
   return {c0, c1, c2, c3};
 }
 template <class R> RTX_DEV R u24(uint32_t x) { return R(x >> 8) * R(1.0 / 16777216.0); }
+template <class R> RTX_DEV R u16hi(uint32_t x) { return (R(x >> 16) + R(0.5)) * R(1.0 / 65536.0); }
+template <class R> RTX_DEV R u16lo(uint32_t x) { return (R(x & 0xffffu) + R(0.5)) * R(1.0 / 65536.0); }
 
 // Uniform direction on the unit sphere from two uniforms (same law as the reference's
 // normalised rejection sample, ref: engine/renderer.cpp:45-56).
@@ -566,7 +574,7 @@ template <class R> RTX_DEV R power_heuristic(R a, R b) { R a2 = a * a, b2 = b * 
 // ------------------------------------------------------------------------------------------
 template <class R> struct LightPick { V3<R> pos, n, Le; R pdf, dist; bool valid; };
 
-template <class R> RTX_DEV LightPick<R> sample_light(const DScene<R>& sc, V3<R> from, R rv, R lu, R lv) {
+template <class R> RTX_DEV LightPick<R> sample_light(const DScene<R>& sc, const DMaterial<R>* mats, V3<R> from, R rv, R lu, R lv) {
   LightPick<R> out;
   out.valid = false; out.pdf = R(0); out.dist = R(0);
   out.pos = out.n = out.Le = {R(0), R(0), R(0)};
@@ -601,7 +609,7 @@ template <class R> RTX_DEV LightPick<R> sample_light(const DScene<R>& sc, V3<R> 
     V3<R> local = unit_vector(lu, lv);  // z = 1-2u, phi = 2 pi v: scene.hpp:254-258
     out.pos = mk3(sp.c) + local * sp.radius;
     out.n = local;
-    out.Le = mk3(sc.mats[sp.mat].emission);
+    out.Le = mk3(mats[sp.mat].emission);
     R area = R(4) * Consts<R>::pi * sp.radius * sp.radius;
     out.pdf = R(1) / area;
   } else if (idx < np + ne + nq) {
@@ -692,6 +700,123 @@ template <class R> RTX_DEV V3<R> background(const DScene<R>& sc, const DRenderPa
 }
 
 // ------------------------------------------------------------------------------------------
+// "flat" closest hit for small scenes (single precision only)
+// ------------------------------------------------------------------------------------------
+// Scenes whose bounded primitives are a handful of spheres (every Cornell / environment
+// configuration) need no tree and no per-lane memory traffic: every primitive comes from a
+// wave-uniform (scalar) load and is tested by every lane with predicated, branch-free code.
+// The winner's shading data travel in the candidate itself (4 selects per accepted test), so
+// there is no divergent "which primitive type won" switch afterwards.  Test order and tie
+// rule are the reference's: bounded primitives in leaf order, then planes, quads, disks; a
+// later primitive with equal t wins.
+struct FlatCand {
+  float t;
+  int id;          // type << 24 | index, -1 = nothing yet
+  float a, b, c;   // sphere: centre; plane / quad / disk: outward normal
+  float w;         // sphere: 1 / radius; others: 0
+  int mat;
+};
+
+RTX_DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+
+RTX_DEV void flat_accept(FlatCand& c, bool ok, float t, int id, float a, float b, float cc, float w, int mat) {
+  c.t = ok ? t : c.t; c.id = ok ? id : c.id;
+  c.a = ok ? a : c.a; c.b = ok ? b : c.b; c.c = ok ? cc : c.c; c.w = ok ? w : c.w; c.mat = ok ? mat : c.mat;
+}
+
+// ref: engine/sphere.hpp:71-92 — near root if it lies in range, else far root
+RTX_DEV bool flat_sphere_t(const DSphere<float>& s, const Ray<float>& r, float a, float inv_a, float t_min, float t_max, float& t) {
+  V3<float> oc = r.o - mk3(s.c);
+  float hb = dot(oc, r.d);
+  float cc = len2(oc) - s.radius * s.radius;
+  float disc = hb * hb - a * cc;
+  float sq = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f));
+  float t0 = (-hb - sq) * inv_a, t1 = (-hb + sq) * inv_a;
+  bool ok0 = t0 >= t_min && t0 <= t_max, ok1 = t1 >= t_min && t1 <= t_max;
+  t = ok0 ? t0 : t1;
+  return disc >= 0.f && (ok0 || ok1);
+}
+// ref: engine/primitives.hpp:35-48
+RTX_DEV bool flat_plane_t(const float* p, const float* n, const Ray<float>& r, float t_min, float t_max, float& t) {
+  float denom = n[0] * r.d.x + n[1] * r.d.y + n[2] * r.d.z;
+  float num = (p[0] - r.o.x) * n[0] + (p[1] - r.o.y) * n[1] + (p[2] - r.o.z) * n[2];
+  t = num * rcp_(denom);
+  return fabsf(denom) >= 1e-8f && t >= t_min && t <= t_max;
+}
+// ref: engine/primitives.hpp:274-300
+RTX_DEV bool flat_quad_t(const DQuad<float>& q, const Ray<float>& r, float t_min, float t_max, float& t) {
+  bool ok = flat_plane_t(q.corner, q.n, r, t_min, t_max, t);
+  V3<float> d = at(r, t) - mk3(q.corner);
+  V3<float> eu = mk3(q.eu), ev = mk3(q.ev);
+  float up = dot(d, eu) * rcp_(len2(eu)), vp = dot(d, ev) * rcp_(len2(ev));
+  return ok && up >= 0.f && up <= 1.f && vp >= 0.f && vp <= 1.f;
+}
+// ref: engine/primitives.hpp:396-417
+RTX_DEV bool flat_disk_t(const DDisk<float>& dl, const Ray<float>& r, float t_min, float t_max, float& t) {
+  bool ok = flat_plane_t(dl.c, dl.n, r, t_min, t_max, t);
+  V3<float> d = at(r, t) - mk3(dl.c);
+  return ok && len2(d) <= dl.radius * dl.radius;
+}
+
+RTX_DEV bool flat_closest(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_max, Hit<float>& h) {
+  FlatCand c;
+  c.t = t_max; c.id = -1; c.a = c.b = c.c = c.w = 0.f; c.mat = 0;
+  const float a = len2(r.d), inv_a = rcp_(a);
+  float t;
+  for (int i = 0; i < sc.n_prims; ++i) {   // all spheres in flat scenes, in reference leaf order
+    const int idx = sc.prims[i].index;
+    const DSphere<float>& s = sc.spheres[idx];
+    bool ok = flat_sphere_t(s, r, a, inv_a, t_min, c.t, t);
+    flat_accept(c, ok, t, (PRIM_SPHERE << 24) | idx, s.c[0], s.c[1], s.c[2], rcp_(s.radius), s.mat);
+  }
+  for (int i = 0; i < sc.n_planes; ++i) {
+    const DPlane<float>& pl = sc.planes[i];
+    bool ok = flat_plane_t(pl.p, pl.n, r, t_min, c.t, t);
+    flat_accept(c, ok, t, (PRIM_PLANE << 24) | i, pl.n[0], pl.n[1], pl.n[2], 0.f, pl.mat);
+  }
+  for (int i = 0; i < sc.n_quads; ++i) {
+    const DQuad<float>& q = sc.quads[i];
+    bool ok = flat_quad_t(q, r, t_min, c.t, t);
+    flat_accept(c, ok, t, (PRIM_QUAD << 24) | i, q.n[0], q.n[1], q.n[2], 0.f, -i - 1);
+  }
+  for (int i = 0; i < sc.n_disks; ++i) {
+    const DDisk<float>& q = sc.disks[i];
+    bool ok = flat_disk_t(q, r, t_min, c.t, t);
+    flat_accept(c, ok, t, (PRIM_DISK << 24) | i, q.n[0], q.n[1], q.n[2], 0.f, -1000 - i);
+  }
+  if (c.id < 0) return false;
+  h.t = c.t; h.type = c.id >> 24; h.idx = c.id & 0xffffff; h.mat = c.mat; h.u = 0.f; h.v = 0.f;
+  h.p = at(r, c.t);
+  V3<float> abc = {c.a, c.b, c.c};
+  V3<float> on = c.w != 0.f ? (h.p - abc) * c.w : abc;
+  face_normal(h, r, on);
+  return true;
+}
+
+RTX_DEV bool flat_occluded(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_max) {
+  const float a = len2(r.d), inv_a = rcp_(a);
+  float t;
+  bool any = false;
+  for (int i = 0; i < sc.n_prims; ++i) any |= flat_sphere_t(sc.spheres[sc.prims[i].index], r, a, inv_a, t_min, t_max, t);
+  for (int i = 0; i < sc.n_planes; ++i) any |= flat_plane_t(sc.planes[i].p, sc.planes[i].n, r, t_min, t_max, t);
+  for (int i = 0; i < sc.n_quads; ++i) any |= flat_quad_t(sc.quads[i], r, t_min, t_max, t);
+  for (int i = 0; i < sc.n_disks; ++i) any |= flat_disk_t(sc.disks[i], r, t_min, t_max, t);
+  return any;
+}
+
+// How a kernel instance intersects: MODE_FLAT (float, small sphere-only scenes, no image
+// textures), MODE_TREE (anything: production BVH / linear list, exact operand order in double).
+template <class R, int MODE> RTX_DEV bool trace_closest(const DScene<R>& sc, const Ray<R>& r, R t_min, R t_max, Hit<R>& h, LaneStack st) {
+  if constexpr (MODE == MODE_FLAT) return flat_closest(sc, r, t_min, t_max, h);
+  else if constexpr (MODE == MODE_TREE_UV) return closest_hit<R, true>(sc, r, t_min, t_max, h, st);
+  else return closest_hit<R, false>(sc, r, t_min, t_max, h, st);
+}
+template <class R, int MODE> RTX_DEV bool trace_occluded(const DScene<R>& sc, const Ray<R>& r, R t_min, R t_max, LaneStack st) {
+  if constexpr (MODE == MODE_FLAT) return flat_occluded(sc, r, t_min, t_max);
+  else return occluded(sc, r, t_min, t_max, st);
+}
+
+// ------------------------------------------------------------------------------------------
 // the integrator, one path vertex at a time
 // ------------------------------------------------------------------------------------------
 // Renderer::ray_color_path (ref: engine/renderer.cpp:580-841, use_mnee = false) issues three
@@ -699,12 +824,13 @@ template <class R> RTX_DEV V3<R> background(const DScene<R>& sc, const DRenderPa
 // "look-ahead" closest hit of the ray the NEXT iteration traces again (:797-835).  Here the
 // look-ahead and the next iteration share one trace: `pending` marks that the vertex about to
 // be found still owes the previous vertex its MIS-weighted emission.
+enum : uint32_t { F_SPEC = 1u, F_DIFFUSE = 2u, F_PENDING = 4u, F_ALIVE = 8u };
+
 template <class R> struct PathState {
   Ray<R> ray;
   V3<R> thr, acc;
   R bsdf_pdf;
-  int bounce;
-  bool spec, was_diffuse, pending, alive;
+  uint32_t bounce_flags;   // bounce << 4 | F_*
 };
 
 struct PathKey { uint32_t pixel, seed, sample; };
@@ -719,28 +845,29 @@ template <class R> RTX_DEV void path_begin(PathState<R>& ps, const DCamera<R>& c
   ps.thr = {R(1), R(1), R(1)};
   ps.acc = {R(0), R(0), R(0)};
   ps.bsdf_pdf = R(0);
-  ps.bounce = 0;
-  ps.spec = false; ps.was_diffuse = false; ps.pending = false; ps.alive = true;
+  ps.bounce_flags = F_ALIVE;
 }
 
-struct StepCounts { uint32_t closest, shadow, segments; };
+// What one vertex did, for the statistics: bit 0 = a shadow ray was cast, bit 1 = the vertex was shaded.
+enum : uint32_t { STEP_SHADOW = 1u, STEP_SHADED = 2u };
 
 // Advance one vertex: trace ps.ray, settle the previous vertex's pending MIS term, shade.
-template <class R> RTX_DEV void path_step(PathState<R>& ps, const DScene<R>& sc, const DRenderParams& P, PathKey key, LaneStack st, StepCounts& cnt) {
+// `mats` is the material table (LDS copy when the kernel staged one).
+template <class R, int MODE> RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMaterial<R>* mats, const DRenderParams& P, PathKey key, LaneStack st) {
   const bool nee = P.use_nee != 0, mis = P.use_mis != 0;
   const bool env_is = sc.env.importance != 0;
-  const bool want_uv = sc.n_images > 0;
+  uint32_t did = 0;
+  const int bounce = (int)(ps.bounce_flags >> 4);
+  const bool was_spec = ps.bounce_flags & F_SPEC, was_diffuse = ps.bounce_flags & F_DIFFUSE, pending = ps.bounce_flags & F_PENDING;
   Hit<R> rec;
-  cnt.closest++;
-  bool hit = want_uv ? closest_hit<R, true>(sc, ps.ray, R(0.001), R(1e9), rec, st)
-                     : closest_hit<R, false>(sc, ps.ray, R(0.001), R(1e9), rec, st);
+  const bool hit = trace_closest<R, MODE>(sc, ps.ray, R(0.001), R(1e9), rec, st);
 
-  if (ps.pending) {  // ref: engine/renderer.cpp:797-835, evaluated on the shared trace
+  if (pending) {  // ref: engine/renderer.cpp:797-835, evaluated on the shared trace
     if (hit) {
       // A quad/disk light id is negative; the reference indexes its material array with it
       // (undefined behaviour).  Defined here as "not emissive": the arrival branch weights it.
       if (rec.mat >= 0) {
-        const DMaterial<R>& nm = sc.mats[rec.mat];
+        const DMaterial<R>& nm = mats[rec.mat];
         if (is_emissive(nm)) {
           R cl = abs_(dot(rec.n, -ps.ray.d));
           R lpa = light_pdf(sc, rec.p);
@@ -756,23 +883,21 @@ template <class R> RTX_DEV void path_step(PathState<R>& ps, const DScene<R>& sc,
       R ep = env_light_pdf(sc, ps.ray.d);
       if (ep > R(0)) { R w = power_heuristic(ps.bsdf_pdf, ep); ps.acc = ps.acc + (ps.thr * ee) * w; }
     }
-    ps.pending = false;
   }
-  if (ps.bounce >= P.max_depth) { ps.alive = false; return; }
+  if (bounce >= P.max_depth) { ps.bounce_flags = 0; return did; }
 
-  const int bounce = ps.bounce;
   if (!hit) {  // ref: engine/renderer.cpp:591-606
-    bool handled = nee && mis && ps.was_diffuse && env_is;
+    bool handled = nee && mis && was_diffuse && env_is;
     if (!handled) ps.acc = ps.acc + ps.thr * background(sc, P, ps.ray);
-    ps.alive = false;
-    return;
+    ps.bounce_flags = 0;
+    return did;
   }
-  cnt.segments++;
+  did |= STEP_SHADED;
   if (rec.mat < 0) {  // area light, ref: engine/renderer.cpp:609-630
     V3<R> Le = area_light_emission(sc, rec.mat);
-    if (bounce == 0 || ps.spec || !nee) {
+    if (bounce == 0 || was_spec || !nee) {
       ps.acc = ps.acc + ps.thr * Le;
-    } else if (mis && ps.was_diffuse && ps.bsdf_pdf > R(0)) {
+    } else if (mis && was_diffuse && ps.bsdf_pdf > R(0)) {
       R cl = abs_(dot(rec.n, -normalize(ps.ray.d)));
       R lpa = light_pdf(sc, rec.p);
       if (lpa > R(0) && cl > R(0)) {
@@ -781,25 +906,22 @@ template <class R> RTX_DEV void path_step(PathState<R>& ps, const DScene<R>& sc,
         ps.acc = ps.acc + (ps.thr * Le) * w;
       }
     }
-    ps.alive = false;
-    return;
+    ps.bounce_flags = 0;
+    return did;
   }
-  const DMaterial<R>& m = sc.mats[rec.mat];
+  const DMaterial<R>& m = mats[rec.mat];
   V3<R> surf = albedo_at(sc, m, rec);
-  if (bounce == 0 || ps.spec || !nee) ps.acc = ps.acc + ps.thr * mk3(m.emission);
+  if (bounce == 0 || was_spec || !nee) ps.acc = ps.acc + ps.thr * mk3(m.emission);
 
   V3<R> sdir = {R(0), R(0), R(0)};
   V3<R> atten = surf;
-  ps.spec = false; ps.was_diffuse = false; ps.bsdf_pdf = R(0);
-  const uint32_t blk = 1u + 2u * (uint32_t)bounce;
-  U4 ra = {0, 0, 0, 0};
-  const bool lamb = m.type == MAT_LAMBERTIAN;
-  if ((lamb && nee) || bounce > 3) ra = philox4x32_10(key.sample, blk, key.pixel, key.seed);
-  U4 rb = philox4x32_10(key.sample, blk + 1u, key.pixel, key.seed);
+  uint32_t flags = F_ALIVE;
+  R bsdf_pdf = R(0);
+  const U4 rn = philox4x32_10(key.sample, 1u + (uint32_t)bounce, key.pixel, key.seed);
 
-  if (lamb) {
+  if (m.type == MAT_LAMBERTIAN) {
     if (nee) {  // ref: engine/renderer.cpp:654-714
-      LightPick<R> ls = sample_light(sc, rec.p, u24<R>(ra.x), u24<R>(ra.y), u24<R>(ra.z));
+      LightPick<R> ls = sample_light(sc, mats, rec.p, u16hi<R>(rn.z), u16hi<R>(rn.x), u16lo<R>(rn.x));
       if (ls.valid) {
         bool is_env = ls.dist > R(1e5);
         V3<R> ldir; R ldist;
@@ -807,9 +929,9 @@ template <class R> RTX_DEV void path_step(PathState<R>& ps, const DScene<R>& sc,
         else { V3<R> tl = ls.pos - rec.p; ldist = len(tl); ldir = tl * (R(1) / ldist); }
         R cs = dot(rec.n, ldir);
         if (cs > R(0)) {
-          cnt.shadow++;
+          did |= STEP_SHADOW;
           Ray<R> sr = {rec.p, ldir};
-          bool occ = occluded(sc, sr, R(0.001), is_env ? R(1e9) : (ldist - R(0.001)), st);
+          bool occ = trace_occluded<R, MODE>(sc, sr, R(0.001), is_env ? R(1e9) : (ldist - R(0.001)), st);
           if (!occ) {
             R lps; bool ok = true;
             if (is_env) lps = ls.pdf;
@@ -827,37 +949,41 @@ template <class R> RTX_DEV void path_step(PathState<R>& ps, const DScene<R>& sc,
         }
       }
     }
-    sdir = rec.n + unit_vector(u24<R>(rb.x), u24<R>(rb.y));   // ref: engine/renderer.cpp:737-743
+    sdir = rec.n + unit_vector(u16hi<R>(rn.y), u16lo<R>(rn.y));   // ref: engine/renderer.cpp:737-743
     if (len2(sdir) < R(1e-8)) sdir = rec.n;
     sdir = normalize(sdir);
-    ps.bsdf_pdf = dot(rec.n, sdir) / Consts<R>::pi;
-    ps.was_diffuse = true;
+    bsdf_pdf = dot(rec.n, sdir) / Consts<R>::pi;
+    flags |= F_DIFFUSE;
   } else if (m.type == MAT_METAL) {  // ref: engine/renderer.cpp:747-759 (below-surface directions continue)
-    ps.spec = true;
+    bool spec = true;
     V3<R> refl = reflect(normalize(ps.ray.d), rec.n);
-    if (m.fuzz > R(0)) { refl = refl + unit_vector(u24<R>(rb.x), u24<R>(rb.y)) * m.fuzz; ps.spec = m.fuzz < R(0.1); }
+    if (m.fuzz > R(0)) { refl = refl + unit_vector(u16hi<R>(rn.y), u16lo<R>(rn.y)) * m.fuzz; spec = m.fuzz < R(0.1); }
     sdir = refl;
+    if (spec) flags |= F_SPEC;
   } else {  // dielectric, ref: engine/renderer.cpp:761-778
-    ps.spec = true;
+    flags |= F_SPEC;
     atten = {R(1), R(1), R(1)};
     R ratio = rec.front ? (R(1) / m.ior) : m.ior;
     V3<R> ud = normalize(ps.ray.d);
     R ct = min_(dot(-ud, rec.n), R(1));
     R sn = sqrt_(R(1) - ct * ct);
-    if (ratio * sn > R(1) || schlick(ct, ratio) > u24<R>(rb.z)) sdir = reflect(ud, rec.n);
+    if (ratio * sn > R(1) || schlick(ct, ratio) > u16hi<R>(rn.w)) sdir = reflect(ud, rec.n);
     else sdir = refract(ud, rec.n, ratio);
   }
   ps.thr = ps.thr * atten;
   if (bounce > 3) {  // ref: engine/renderer.cpp:785-790
     R p = max_(ps.thr.x, max_(ps.thr.y, ps.thr.z));
-    if (p < R(0.01) || u24<R>(ra.w) > p) { ps.alive = false; return; }
+    if (p < R(0.01) || u16lo<R>(rn.z) > p) { ps.bounce_flags = 0; return did; }
     ps.thr = ps.thr * (R(1) / p);
   }
   ps.ray.o = rec.p;
   ps.ray.d = sdir;
-  ps.pending = nee && mis && !ps.spec && ps.bsdf_pdf > R(0);
-  ps.bounce = bounce + 1;
-  if (ps.bounce >= P.max_depth && !ps.pending) ps.alive = false;
+  ps.bsdf_pdf = bsdf_pdf;
+  const bool next_pending = nee && mis && !(flags & F_SPEC) && bsdf_pdf > R(0);
+  if (next_pending) flags |= F_PENDING;
+  if (bounce + 1 >= P.max_depth && !next_pending) flags = 0;
+  ps.bounce_flags = flags ? (((uint32_t)(bounce + 1) << 4) | flags) : 0u;
+  return did;
 }
 
 }  // namespace rtx

@@ -36,18 +36,31 @@ struct HostScene {
   double build_seconds = 0.0;
   std::vector<DeviceBuffer> pool;   // owns every device allocation of the scene
   int upload(const rtx_scene_desc& d, std::string& err);
+  // Which intersection mode the integrator kernels use for this scene.
+  int fused_mode(bool f64) const {
+    const bool spheres_only = dev_f.n_tris == 0 && dev_f.n_boxes == 0 && dev_f.n_spheres <= kFlatMaxSpheres;
+    if (!f64 && spheres_only && dev_f.n_images == 0) return MODE_FLAT;
+    return dev_f.n_images > 0 ? MODE_TREE_UV : MODE_TREE;
+  }
   void release();
 };
 
 // kernel launchers (kernels_f32.hip / kernels_f64.hip)
-void launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
-                         int grid, size_t lds_bytes, hipStream_t stream);
-void launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters,
-                         int grid, size_t lds_bytes, hipStream_t stream);
+struct FusedLaunch {
+  int mode;             // MODE_TREE / MODE_TREE_UV / MODE_FLAT (pt_device.hpp)
+  bool lds_mats;        // material table staged in LDS
+  int grid;
+  size_t lds_bytes;     // dynamic LDS per workgroup
+  int stack_first_int;  // offset (in ints) of the traversal stacks inside the dynamic LDS
+};
+int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
+                        const FusedLaunch& L, hipStream_t stream);
+int launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters,
+                        const FusedLaunch& L, hipStream_t stream);
 void launch_film_reduce(const float* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream);
 void launch_film_reduce(const double* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream);
-void launch_trace_fast(const DScene<float>& sc, const double* rays8, unsigned long long n, DHitOut* out, size_t lds_bytes, hipStream_t stream);
-void launch_trace_fast(const DScene<double>& sc, const double* rays8, unsigned long long n, DHitOut* out, size_t lds_bytes, hipStream_t stream);
+int launch_trace_fast(const DScene<float>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream);
+int launch_trace_fast(const DScene<double>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream);
 void launch_trace_ref(const DScene<double>& sc, const DSceneRef& ref, const double* rays8, unsigned long long n, DHitOut* out, hipStream_t stream);
 void launch_selftest(float* out, int n, hipStream_t stream);
 

@@ -1,28 +1,39 @@
-// Kernel templates + their launchers.  Instantiated for double in kernels_f64.hip (built with
-// -ffp-contract=off) and for float in kernels_f32.hip.
+// Kernel templates.  Instantiated for double in kernels_f64.hip (built with -ffp-contract=off)
+// and for float in kernels_f32.hip.
 #pragma once
 
 #include "pt_device.hpp"
 
 namespace rtx {
 
+// Dynamic LDS of a workgroup: [material table (when staged)] [traversal stacks, [level][lane]].
 extern __shared__ int lds_dyn[];
 
-RTX_DEV LaneStack lane_stack() {
+RTX_DEV LaneStack lane_stack(int first_int) {
   LaneStack st;
-  st.base = lds_dyn + threadIdx.x;
+  st.base = lds_dyn + first_int + threadIdx.x;
   st.stride = blockDim.x;
   return st;
 }
 
-RTX_DEV unsigned long long wave_sum(unsigned long long v) {
+RTX_DEV uint32_t wave_max(uint32_t v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), off, 64);
-    unsigned hi = __shfl_xor((unsigned)(v >> 32), off, 64);
-    v += ((unsigned long long)hi << 32) | lo;
+    uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+    v = o > v ? o : v;
   }
   return v;
+}
+
+template <class R> constexpr int mat_ints() { return (int)(sizeof(DMaterial<R>) / sizeof(int)); }
+
+// Copy the material table into LDS (it is indexed per lane at every shaded vertex).
+template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& sc) {
+  const int n = sc.n_mats * mat_ints<R>();
+  const int* src = reinterpret_cast<const int*>(sc.mats);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) lds_dyn[i] = src[i];
+  __syncthreads();
+  return reinterpret_cast<const DMaterial<R>*>(lds_dyn);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -32,64 +43,79 @@ RTX_DEV unsigned long long wave_sum(unsigned long long v) {
 // is empty.  Chunk sums go to `partial`; film_reduce_kernel adds them in chunk order, which
 // makes the film independent of grid size, scheduling and sharding.
 // ------------------------------------------------------------------------------------------
-template <class R>
-__global__ __launch_bounds__(kBlock) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
-                                                               DCounters* __restrict__ counters) {
-  const unsigned long long npix = (unsigned long long)P.rows * (unsigned long long)P.width;
-  const unsigned long long n_items = npix * (unsigned long long)P.n_chunks;
-  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-  unsigned long long next = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  LaneStack st = lane_stack();
+// The flat instance is capped at 128 VGPRs (4 waves per SIMD): measured 7 % faster than the
+// compiler's free choice of 140 despite 32 bytes of scratch per lane.
+#ifndef RTX_FLAT_MIN_WAVES
+#define RTX_FLAT_MIN_WAVES 4
+#endif
+template <class R, int MODE, bool LDS_MATS>
+__global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? RTX_FLAT_MIN_WAVES : 1)) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
+                                                               DCounters* __restrict__ counters, int stack_first_int) {
+  const DMaterial<R>* mats = sc.mats;
+  if constexpr (LDS_MATS) mats = stage_materials(sc);
+  const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
+  const uint32_t n_items = npix * (uint32_t)P.n_chunks;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  uint32_t next = blockIdx.x * blockDim.x + threadIdx.x;
+  LaneStack st = lane_stack(stack_first_int);
 
-  StepCounts cnt = {0, 0, 0};
-  uint32_t n_samples = 0;
+  // Statistics: every trip adds the number of active lanes to wave-uniform counters.  A lane
+  // that leaves the loop stops adding, so the lane that stays longest holds the wave's totals:
+  // they are recovered with a max over the lanes at the end.
+  uint32_t w_steps = 0, w_shadow = 0, w_shaded = 0, w_samples = 0;
   PathState<R> ps;
-  ps.alive = false;
+  ps.bounce_flags = 0;
   V3<R> sum = {R(0), R(0), R(0)};
-  unsigned long long cur = 0;
-  int s = 0, s_end = 0, x = 0, y = 0;
+  uint32_t cur = 0, xy = 0;
+  int s = 0, s_end = 0;
   PathKey key = {0u, P.seed, 0u};
 
   auto fetch = [&]() -> bool {
     if (next >= n_items) return false;
     cur = next;
     next += stride;
-    unsigned long long pix = cur % npix;
-    int chunk = (int)(cur / npix);
-    int row_local = (int)(pix / (unsigned long long)P.width);
-    x = (int)(pix - (unsigned long long)row_local * P.width);
-    y = P.shard_index + row_local * P.shard_count;
-    key.pixel = (uint32_t)(y * P.width + x);
-    s = chunk * P.chunk_spp;
+    uint32_t chunk = cur / npix;
+    uint32_t pix = cur - chunk * npix;
+    uint32_t row_local = pix / (uint32_t)P.width;
+    uint32_t x = pix - row_local * (uint32_t)P.width;
+    uint32_t y = (uint32_t)P.shard_index + row_local * (uint32_t)P.shard_count;
+    xy = (y << 16) | x;
+    key.pixel = y * (uint32_t)P.width + x;
+    s = (int)chunk * P.chunk_spp;
     s_end = s + P.chunk_spp < P.spp ? s + P.chunk_spp : P.spp;
     sum = {R(0), R(0), R(0)};
     return s < s_end;
   };
 
   bool active = fetch();
-  if (active) { key.sample = (uint32_t)s++; path_begin(ps, cam, P, x, y, key); n_samples++; }
+  if (active) { key.sample = (uint32_t)s++; path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key); }
+  w_samples += (uint32_t)__popcll(__ballot(active));
   while (active) {
-    path_step(ps, sc, P, key, st, cnt);
-    if (!ps.alive) {
+    w_steps += (uint32_t)__popcll(__ballot(1));
+    const uint32_t did = path_step<R, MODE>(ps, sc, mats, P, key, st);
+    w_shadow += (uint32_t)__popcll(__ballot((did & STEP_SHADOW) != 0));
+    w_shaded += (uint32_t)__popcll(__ballot((did & STEP_SHADED) != 0));
+    bool started = false;
+    if (!(ps.bounce_flags & F_ALIVE)) {
       sum = sum + ps.acc;
       if (s == s_end) {
-        R* o = partial + cur * 3ull;
+        R* o = partial + (size_t)cur * 3u;
         o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
         active = fetch();
         if (!active) break;
       }
       key.sample = (uint32_t)s++;
-      path_begin(ps, cam, P, x, y, key);
-      n_samples++;
+      path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key);
+      started = true;
     }
+    w_samples += (uint32_t)__popcll(__ballot(started));   // outside the divergent branch: counters must be added in uniform flow
   }
-
-  unsigned long long a = wave_sum(n_samples), b = wave_sum(cnt.closest), c = wave_sum(cnt.shadow), d = wave_sum(cnt.segments);
+  w_samples = wave_max(w_samples); w_steps = wave_max(w_steps); w_shadow = wave_max(w_shadow); w_shaded = wave_max(w_shaded);
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&counters->samples, a);
-    atomicAdd(&counters->closest, b);
-    atomicAdd(&counters->shadow, c);
-    atomicAdd(&counters->segments, d);
+    atomicAdd(&counters->samples, (unsigned long long)w_samples);
+    atomicAdd(&counters->closest, (unsigned long long)w_steps);
+    atomicAdd(&counters->shadow, (unsigned long long)w_shadow);
+    atomicAdd(&counters->segments, (unsigned long long)w_shaded);
   }
 }
 
@@ -104,15 +130,15 @@ __global__ void film_reduce_kernel(const R* __restrict__ partial, float* __restr
   film[i] = (float)(acc * (R(1) / R(spp)));
 }
 
-// Closest hit of a ray batch through the production BVH (the structure the integrator walks).
-template <class R>
+// Closest hit of a ray batch through the structure the integrator walks.
+template <class R, int MODE>
 __global__ __launch_bounds__(kBlock) void trace_fast_kernel(DScene<R> sc, const double* __restrict__ rays8, unsigned long long n, DHitOut* __restrict__ out) {
   unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double* q = rays8 + i * 8ull;
   Ray<R> r = {{R(q[0]), R(q[1]), R(q[2])}, {R(q[3]), R(q[4]), R(q[5])}};
   Hit<R> h;
-  bool ok = closest_hit<R, true>(sc, r, R(q[6]), R(q[7]), h, lane_stack());
+  bool ok = trace_closest<R, MODE>(sc, r, R(q[6]), R(q[7]), h, lane_stack(0));
   DHitOut o;
   o.hit = ok; o.prim_type = ok ? h.type : -1; o.prim_index = ok ? h.idx : -1;
   o.material_id = ok ? h.mat : 0; o.front_face = ok ? h.front : 0; o.pad = 0;

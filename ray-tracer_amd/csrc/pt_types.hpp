@@ -78,6 +78,11 @@ constexpr int kBlock = 256;          // threads per workgroup of the render / tr
 constexpr int kLinearMaxPrims = 12;  // at or below this many bounded primitives: no tree walk
 constexpr int kStackDepth = 48;      // per-lane traversal stack entries (LDS)
 
+// How a kernel instance intersects (see pt_device.hpp).
+enum { MODE_TREE = 0, MODE_TREE_UV = 1, MODE_FLAT = 2 };
+constexpr int kFlatMaxSpheres = 16;   // flat mode: sphere-only bounded primitives, at most this many
+constexpr size_t kMaxLdsMaterialBytes = 32768;
+
 enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_TRIANGLE = 2, PRIM_BOX = 3, PRIM_QUAD = 4, PRIM_DISK = 5 };
 enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2 };
 enum { TEX_SOLID = 0, TEX_CHECKER = 1, TEX_IMAGE = 2 };

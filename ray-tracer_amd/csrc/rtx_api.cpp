@@ -151,7 +151,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   if (!c->has_camera) return fail(RTX_ERR_NOT_READY, "render before set_camera");
   if (s->width <= 0 || s->height <= 0 || s->samples_per_pixel <= 0 || s->max_depth < 0)
     return fail(RTX_ERR_INVALID_ARGUMENT, "bad settings: %dx%d spp=%d depth=%d", s->width, s->height, s->samples_per_pixel, s->max_depth);
-  if ((long long)s->width * s->height > 0x7fffffffLL) return fail(RTX_ERR_INVALID_ARGUMENT, "film too large");
+  if (s->width > 65535 || s->height > 65535) return fail(RTX_ERR_INVALID_ARGUMENT, "film too large (max 65535 per side)");
   if (s->use_mnee) return fail(RTX_ERR_UNSUPPORTED, "use_mnee: manifold next-event estimation is not implemented by this backend");
   const int sc_n = s->shard_count > 0 ? s->shard_count : 1;
   if (s->shard_index < 0 || s->shard_index >= sc_n) return fail(RTX_ERR_INVALID_ARGUMENT, "shard %d of %d", s->shard_index, sc_n);
@@ -196,21 +196,31 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   HIP_TRY(hipEventRecord(c->ev0, stream));
   if (pipeline == RTX_PIPELINE_FUSED) {
     const size_t elem = f64 ? sizeof(double) : sizeof(float);
-    if (!c->partial.ensure((size_t)P.n_chunks * npix * 3 * elem)) return fail(RTX_ERR_OUT_OF_MEMORY, "chunk-sum buffer (%llu bytes)", (unsigned long long)((size_t)P.n_chunks * npix * 3 * elem));
     const unsigned long long items = npix * (unsigned long long)P.n_chunks;
-    const size_t lds = needs_stack ? (size_t)kStackDepth * kBlock * sizeof(int) : 0;
-    // Persistent grid: enough blocks to fill every CU at the kernel's occupancy, no more.
-    const int blocks_per_cu = needs_stack ? 3 : 4;
-    int grid = (int)std::min<unsigned long long>((items + kBlock - 1) / kBlock, (unsigned long long)c->n_cus * blocks_per_cu);
+    if (items >= 0x7fffffffull) return fail(RTX_ERR_INVALID_ARGUMENT, "film too large for one launch (%llu work items)", items);
+    if (!c->partial.ensure((size_t)items * 3 * elem)) return fail(RTX_ERR_OUT_OF_MEMORY, "chunk-sum buffer (%llu bytes)", (unsigned long long)(items * 3 * elem));
+    FusedLaunch L;
+    L.mode = c->scene.fused_mode(f64);
+    const size_t mat_bytes = (size_t)c->scene.dev_f.n_mats * (f64 ? sizeof(DMaterial<double>) : sizeof(DMaterial<float>));
+    L.lds_mats = mat_bytes <= kMaxLdsMaterialBytes;
+    if (!L.lds_mats) L.mode = MODE_TREE_UV;
+    L.stack_first_int = L.lds_mats ? (int)((mat_bytes / 4 + 3) & ~(size_t)3) : 0;
+    const bool stack = L.mode != MODE_FLAT && needs_stack;
+    L.lds_bytes = ((size_t)L.stack_first_int + (stack ? (size_t)kStackDepth * kBlock : 0)) * sizeof(int);
+    // Persistent grid: enough workgroups to fill every CU at the kernel's occupancy, no more.
+    const int blocks_per_cu = stack ? 3 : 6;
+    L.grid = (int)std::min<unsigned long long>((items + kBlock - 1) / kBlock, (unsigned long long)c->n_cus * blocks_per_cu);
+    int lrc;
     if (f64) {
-      launch_render_fused(c->scene.dev_d, c->cam_d, P, (double*)c->partial.ptr, (DCounters*)c->counters.ptr, grid, lds, stream);
+      lrc = launch_render_fused(c->scene.dev_d, c->cam_d, P, (double*)c->partial.ptr, (DCounters*)c->counters.ptr, L, stream);
       HIP_TRY(hipEventRecord(c->evm, stream));
       launch_film_reduce((const double*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
     } else {
-      launch_render_fused(c->scene.dev_f, c->cam_f, P, (float*)c->partial.ptr, (DCounters*)c->counters.ptr, grid, lds, stream);
+      lrc = launch_render_fused(c->scene.dev_f, c->cam_f, P, (float*)c->partial.ptr, (DCounters*)c->counters.ptr, L, stream);
       HIP_TRY(hipEventRecord(c->evm, stream));
       launch_film_reduce((const float*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
     }
+    if (lrc != 0) return fail(RTX_ERR_UNSUPPORTED, "no kernel instance for mode %d", L.mode);
     st.kernel_launches = 2;
   } else {
     std::string err;
@@ -256,8 +266,8 @@ static int trace_impl(rtx_ctx* c, const double* rays8, size_t n, rtx_hit* out, i
   HIP_TRY(hipMemcpyAsync(c->rays.ptr, rays8, n * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   const size_t lds = c->scene.n_prims > kLinearMaxPrims ? (size_t)kStackDepth * kBlock * sizeof(int) : 0;
   if (mode == 0) launch_trace_ref(c->scene.dev_d, c->scene.dev_ref, (const double*)c->rays.ptr, n, (DHitOut*)c->hits.ptr, c->stream);
-  else if (mode == 1) launch_trace_fast(c->scene.dev_f, (const double*)c->rays.ptr, n, (DHitOut*)c->hits.ptr, lds, c->stream);
-  else launch_trace_fast(c->scene.dev_d, (const double*)c->rays.ptr, n, (DHitOut*)c->hits.ptr, lds, c->stream);
+  else if (mode == 1) launch_trace_fast(c->scene.dev_f, (const double*)c->rays.ptr, n, (DHitOut*)c->hits.ptr, c->scene.fused_mode(false) == MODE_FLAT ? MODE_FLAT : MODE_TREE_UV, lds, c->stream);
+  else launch_trace_fast(c->scene.dev_d, (const double*)c->rays.ptr, n, (DHitOut*)c->hits.ptr, MODE_TREE_UV, lds, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, c->hits.ptr, n * sizeof(DHitOut), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

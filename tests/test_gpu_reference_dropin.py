@@ -1,0 +1,36 @@
+"""End-to-end drop-in check on the GPU box with the REAL reference in the loop.
+
+oracle/_ref/ref_hip_driver (built where /root/reference exists; the binary travels) loads a scene
+with the reference's own SceneLoader, hands the reference's Scene/Camera objects to the HIP
+backend through ray-tracer_amd/host/reference_adapter.hpp + the C ABI, and also renders the
+same scene with the reference's own Renderer::render on the host cores (use_mnee = false).
+The two films must agree within the Monte-Carlo tolerance at equal spp."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, rel_mse
+
+pytestmark = pytest.mark.gpu
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_hip_driver")
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/ref_hip_driver not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("name,depth", [("cornell_box", 500), ("cornell_box_quad", 50), ("caustics_test", 16), ("environment_demo", 50)])
+def test_reference_loader_feeds_hip_backend_and_matches_reference_renderer(name, depth, tmp_path):
+    fx = np.load(os.path.join(GOLDEN, "converged", name + ".npz"))
+    W, H, N = int(fx["W"]), int(fx["H"]), int(fx["N"])
+    prefix = str(tmp_path / name)
+    out = subprocess.run([DRIVER, os.path.join(GOLDEN, "scenes", name + ".json"), str(W), str(H), str(N), str(N), str(depth), "16", prefix, "99"],
+                         cwd=GOLDEN, check=True, capture_output=True, text=True, timeout=110).stdout
+    gpu = np.fromfile(prefix + "_gpu.bin", dtype=np.float32).reshape(H, W, 3).astype(np.float64)
+    cpu = np.fromfile(prefix + "_cpu.bin", dtype=np.float64).reshape(H, W, 3)
+    ref = fx["film"].astype(np.float64)          # the reference at 4N spp, other seed
+    floor = max(float(fx["noise_floor_relmse"]), rel_mse(cpu, ref))
+    assert rel_mse(gpu, ref) <= 1.25 * floor, (rel_mse(gpu, ref), floor)
+    mg, mc = np.clip(gpu, 0, 1).mean(axis=(0, 1)), np.clip(ref, 0, 1).mean(axis=(0, 1))
+    assert np.all(np.abs(mg - mc) / mc < 0.015), (mg, mc)
+    lines = [l for l in out.splitlines() if l.startswith("@@")]
+    print(name, *lines)
