@@ -10,6 +10,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pt_types.hpp"
 
 namespace rtx {
@@ -326,7 +328,7 @@ template <class R> RTX_DEV R slab_entry(const DNode2<R>& nd, const Ray<R>& r, V3
   t0 = (nd.lo[2] - r.o.z) * inv.z; t1 = (nd.hi[2] - r.o.z) * inv.z;
   lo = max_(lo, min_(t0, t1)); hi = min_(hi, max_(t0, t1));
   lo = max_(lo, t_min); hi = min_(hi, t_max);
-  ok = lo <= hi;
+  ok = lo < hi;   // strict: a box that is flat along an axis is never entered, as in the reference (bvh.hpp:43)
   return lo;
 }
 
@@ -378,10 +380,101 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
   return c.type >= 0;
 }
 
+// Single-precision walk over the child-pair records: one 64-byte fetch per step, nearer child
+// first, farther child on the LDS stack, leaves tested as soon as their box is hit.
+// On an exact tie in t the primitive later in the reference's leaf order wins, whatever the
+// visiting order (`rank` = position in that order).
+RTX_DEV bool pair_slab(const float* lo, const float* hi, const Ray<float>& r, V3<float> inv, float t_min, float t_max, float& entry) {
+  float t0 = (lo[0] - r.o.x) * inv.x, t1 = (hi[0] - r.o.x) * inv.x;
+  float a = fminf(t0, t1), b = fmaxf(t0, t1);
+  t0 = (lo[1] - r.o.y) * inv.y; t1 = (hi[1] - r.o.y) * inv.y;
+  a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
+  t0 = (lo[2] - r.o.z) * inv.z; t1 = (hi[2] - r.o.z) * inv.z;
+  a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
+  a = fmaxf(a, t_min); b = fminf(b, t_max);
+  entry = a;
+  return a < b;
+}
+
+template <bool ANY> RTX_DEV void pair_leaf(const DScene<float>& sc, int code, const Ray<float>& r, float t_min, Cand<float>& c, int& rank) {
+  const int first = (~code) >> 2, count = (~code) & 3;
+  for (int i = 0; i < count; ++i) {
+    const int pos = first + i;
+    const DLeafPrim lp = sc.leaf_prims[pos];
+    float t, u, v;
+    bool ok = false;
+    if (lp.type == PRIM_TRIANGLE) {
+      V3<float> v0 = mk3(lp.v0);
+      V3<float> e1 = mk3(lp.v1) - v0, e2 = mk3(lp.v2) - v0;
+      V3<float> h = cross(r.d, e2);
+      float a = dot(e1, h);
+      float f = 1.0f / a;
+      V3<float> s = r.o - v0;
+      u = f * dot(s, h);
+      V3<float> q = cross(s, e1);
+      v = f * dot(r.d, q);
+      t = f * dot(e2, q);
+      ok = fabsf(a) >= 1e-8f && u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= t_min && t <= c.t;
+      ok = ok && !(t == c.t && pos < rank);
+      if (ok) { c.t = t; c.type = PRIM_TRIANGLE; c.idx = lp.index; c.uv_kind = 1; c.ua = u; c.ub = v; rank = pos; }
+    } else {
+      Cand<float> trial = c;
+      test_bounded(sc, lp.type, lp.index, r, t_min, trial);
+      const bool changed = trial.type == lp.type && trial.idx == lp.index && (trial.t != c.t || c.type != lp.type || c.idx != lp.index);
+      if (changed && !(trial.t == c.t && pos < rank)) { c = trial; rank = pos; }
+    }
+  }
+}
+
+template <bool ANY> RTX_DEV bool walk_pairs(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, LaneStack st) {
+  const V3<float> inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+  int sp = 0, node = 0, rank = -1;
+#ifdef RTX_WALK_STATS
+  int walk_steps = 0;   // diagnostic build: steps per ray come back in hit.u
+#endif
+  for (;;) {
+#ifdef RTX_WALK_STATS
+    ++walk_steps;
+#endif
+    const DNodePair p = sc.pairs[node];
+    float el, er;
+    const bool ok_l = pair_slab(p.lo_l, p.hi_l, r, inv, t_min, c.t, el);
+    const bool ok_r = pair_slab(p.lo_r, p.hi_r, r, inv, t_min, c.t, er);
+    const bool swap = ok_l && ok_r && er < el;
+    const int near = swap ? p.cr : p.cl, far = swap ? p.cl : p.cr;
+    const bool ok_near = swap ? ok_r : ok_l, ok_far = swap ? ok_l : ok_r;
+    const float e_far = swap ? el : er;
+    int go = 0x7fffffff;   // inner node to descend into
+    if (ok_near) {
+      if (near < 0) { pair_leaf<ANY>(sc, near, r, t_min, c, rank); if (ANY && c.type >= 0) return true; }
+      else go = near;
+    }
+    if (ok_far && e_far < c.t) {
+      if (far < 0) { pair_leaf<ANY>(sc, far, r, t_min, c, rank); if (ANY && c.type >= 0) return true; }
+      else if (go == 0x7fffffff) go = far;
+      else if (sp < kStackDepth) st.at(sp++) = far;
+    }
+    if (go != 0x7fffffff) { node = go; continue; }
+    if (sp == 0) break;
+    node = st.at(--sp);
+  }
+#ifdef RTX_WALK_STATS
+  c.ua = (float)walk_steps; c.uv_kind = 1;
+#endif
+  return c.type >= 0;
+}
+
+template <class R, bool ANY> RTX_DEV bool walk_tree(const DScene<R>& sc, const Ray<R>& r, R t_min, Cand<R>& c, LaneStack st) {
+  if constexpr (std::is_same<R, float>::value) {
+    if (sc.n_prims > kLinearMaxPrims) return walk_pairs<ANY>(sc, r, t_min, c, st);
+  }
+  return walk_bounded<R, ANY>(sc, r, t_min, c, st);
+}
+
 template <class R, bool WANT_UV> RTX_DEV bool closest_hit(const DScene<R>& sc, const Ray<R>& r, R t_min, R t_max, Hit<R>& h, LaneStack st) {
   Cand<R> c;
   cand_init(c, t_max);
-  walk_bounded<R, false>(sc, r, t_min, c, st);
+  walk_tree<R, false>(sc, r, t_min, c, st);
   test_unbounded(sc, r, t_min, c);
   if (c.type < 0) return false;
   finalize_hit<R, WANT_UV>(sc, r, c, h);
@@ -392,7 +485,7 @@ template <class R, bool WANT_UV> RTX_DEV bool closest_hit(const DScene<R>& sc, c
 template <class R> RTX_DEV bool occluded(const DScene<R>& sc, const Ray<R>& r, R t_min, R t_max, LaneStack st) {
   Cand<R> c;
   cand_init(c, t_max);
-  if (walk_bounded<R, true>(sc, r, t_min, c, st)) return true;
+  if (walk_tree<R, true>(sc, r, t_min, c, st)) return true;
   R t, u, v;
   bool any = false;
   for (int i = 0; i < sc.n_planes; ++i) any |= plane_t(sc.planes[i], r, t_min, t_max, t);
@@ -851,16 +944,19 @@ template <class R> RTX_DEV void path_begin(PathState<R>& ps, const DCamera<R>& c
 // What one vertex did, for the statistics: bit 0 = a shadow ray was cast, bit 1 = the vertex was shaded.
 enum : uint32_t { STEP_SHADOW = 1u, STEP_SHADED = 2u };
 
-// Advance one vertex: trace ps.ray, settle the previous vertex's pending MIS term, shade.
-// `mats` is the material table (LDS copy when the kernel staged one).
-template <class R, int MODE> RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMaterial<R>* mats, const DRenderParams& P, PathKey key, LaneStack st) {
+// Shade the vertex a trace of ps.ray found (`hit`, `rec`): settle the previous vertex's pending
+// MIS term, add emission, sample a light, scatter, Russian roulette.  The visibility query of
+// the light sample is handed to `shadow(ray, t_max, contribution)`: the fused kernel traces it
+// on the spot, the wavefront pipeline queues it.  `mats` is the material table (an LDS copy when
+// the kernel staged one).
+template <class R, class ShadowFn>
+RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
+                             const DRenderParams& P, PathKey key, ShadowFn&& shadow) {
   const bool nee = P.use_nee != 0, mis = P.use_mis != 0;
   const bool env_is = sc.env.importance != 0;
   uint32_t did = 0;
   const int bounce = (int)(ps.bounce_flags >> 4);
   const bool was_spec = ps.bounce_flags & F_SPEC, was_diffuse = ps.bounce_flags & F_DIFFUSE, pending = ps.bounce_flags & F_PENDING;
-  Hit<R> rec;
-  const bool hit = trace_closest<R, MODE>(sc, ps.ray, R(0.001), R(1e9), rec, st);
 
   if (pending) {  // ref: engine/renderer.cpp:797-835, evaluated on the shared trace
     if (hit) {
@@ -929,23 +1025,24 @@ template <class R, int MODE> RTX_DEV uint32_t path_step(PathState<R>& ps, const 
         else { V3<R> tl = ls.pos - rec.p; ldist = len(tl); ldir = tl * (R(1) / ldist); }
         R cs = dot(rec.n, ldir);
         if (cs > R(0)) {
+          // The reference casts the shadow ray first and evaluates the pdfs only if it is
+          // unoccluded; the contribution does not depend on that order.
           did |= STEP_SHADOW;
-          Ray<R> sr = {rec.p, ldir};
-          bool occ = trace_occluded<R, MODE>(sc, sr, R(0.001), is_env ? R(1e9) : (ldist - R(0.001)), st);
-          if (!occ) {
-            R lps; bool ok = true;
-            if (is_env) lps = ls.pdf;
-            else {
-              R cl = abs_(dot(ls.n, -ldir));
-              ok = cl > R(0);
-              lps = ok ? ls.pdf * ldist * ldist / cl : R(0);
-            }
-            if (ok && lps > R(0)) {
-              R bpl = cs / Consts<R>::pi;
-              R w = mis ? power_heuristic(lps, bpl) : R(1);
-              ps.acc = ps.acc + ((ls.Le * surf) * ps.thr) * (cs / (Consts<R>::pi * lps) * w);
-            }
+          R lps; bool ok = true;
+          if (is_env) lps = ls.pdf;
+          else {
+            R cl = abs_(dot(ls.n, -ldir));
+            ok = cl > R(0);
+            lps = ok ? ls.pdf * ldist * ldist / cl : R(0);
           }
+          V3<R> contrib = {R(0), R(0), R(0)};
+          if (ok && lps > R(0)) {
+            R bpl = cs / Consts<R>::pi;
+            R w = mis ? power_heuristic(lps, bpl) : R(1);
+            contrib = ((ls.Le * surf) * ps.thr) * (cs / (Consts<R>::pi * lps) * w);
+          }
+          Ray<R> sr = {rec.p, ldir};
+          shadow(sr, is_env ? R(1e9) : (ldist - R(0.001)), contrib);
         }
       }
     }
@@ -984,6 +1081,15 @@ template <class R, int MODE> RTX_DEV uint32_t path_step(PathState<R>& ps, const 
   if (bounce + 1 >= P.max_depth && !next_pending) flags = 0;
   ps.bounce_flags = flags ? (((uint32_t)(bounce + 1) << 4) | flags) : 0u;
   return did;
+}
+
+// Fused form: trace, shade, and trace the shadow ray in place.
+template <class R, int MODE> RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMaterial<R>* mats, const DRenderParams& P, PathKey key, LaneStack st) {
+  Hit<R> rec;
+  const bool hit = trace_closest<R, MODE>(sc, ps.ray, R(0.001), R(1e9), rec, st);
+  return path_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<R>& sr, R t_max, V3<R> contrib) {
+    if (!trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st)) ps.acc = ps.acc + contrib;
+  });
 }
 
 }  // namespace rtx

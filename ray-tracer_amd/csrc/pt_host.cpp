@@ -172,6 +172,42 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
     if (n.count > 0) { nodes[i].a = n.first; nodes[i].count = n.count; }
     else { nodes[i].a = n.right; nodes[i].count = 0; }
   }
+  if (std::is_same<R, float>::value && bvh.prims.size() > (size_t)kLinearMaxPrims) {
+    // child-pair records, one per inner node, in the order the inner nodes appear in preorder
+    std::vector<int32_t> pair_of(bvh.nodes.size(), -1);
+    int32_t np = 0;
+    for (size_t i = 0; i < bvh.nodes.size(); ++i) if (bvh.nodes[i].count == 0) pair_of[i] = np++;
+    std::vector<DNodePair> pairs((size_t)np);
+    auto code = [&](int32_t child) -> int32_t {
+      const DNodeRef& c = bvh.nodes[child];
+      return c.count > 0 ? ~((c.first << 2) | c.count) : pair_of[child];
+    };
+    auto box = [&](int32_t child, float* lo, float* hi) {
+      const DNodeRef& c = bvh.nodes[child];
+      for (int a = 0; a < 3; ++a) {
+        if (c.lo[a] != c.hi[a]) { lo[a] = f_down(c.lo[a]); hi[a] = f_up(c.hi[a]); }
+        else { lo[a] = (float)c.lo[a]; hi[a] = (float)c.hi[a]; }
+      }
+    };
+    for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+      const DNodeRef& n = bvh.nodes[i];
+      if (n.count > 0) continue;
+      DNodePair& p = pairs[(size_t)pair_of[i]];
+      box(n.left, p.lo_l, p.hi_l); box(n.right, p.lo_r, p.hi_r);
+      p.cl = code(n.left); p.cr = code(n.right); p.pad0 = p.pad1 = 0;
+    }
+    std::vector<DLeafPrim> leaf(bvh.prims.size());
+    for (size_t i = 0; i < bvh.prims.size(); ++i) {
+      DLeafPrim& l = leaf[i];
+      memset(&l, 0, sizeof l);
+      l.type = bvh.prims[i].type; l.index = bvh.prims[i].index;
+      if (l.type == PRIM_TRIANGLE) {
+        const rtx_triangle& t = d.triangles[l.index];
+        cp3(l.v0, t.v0); cp3(l.v1, t.v1); cp3(l.v2, t.v2); l.mat = t.material_id;
+      }
+    }
+    sc.pairs = push(pool, pairs, ok); sc.leaf_prims = push(pool, leaf, ok); sc.n_pairs = np;
+  }
   sc.spheres = push(pool, sph, ok); sc.planes = push(pool, pls, ok); sc.tris = push(pool, tris, ok); sc.boxes = push(pool, boxes, ok);
   sc.points = push(pool, pts, ok); sc.quads = push(pool, quads, ok); sc.disks = push(pool, disks, ok); sc.mats = push(pool, mats, ok);
   sc.nodes = push(pool, nodes, ok);

@@ -70,6 +70,6 @@ struct WavefrontPool {
   void release();
 };
 int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* d_film,
-                     DCounters* counters, int n_cus, bool needs_stack, hipStream_t stream, uint32_t& launches, std::string& err);
+                     DCounters* counters, int n_cus, int mode, bool needs_stack, hipStream_t stream, uint32_t& launches, std::string& err);
 
 }  // namespace rtx

@@ -32,6 +32,15 @@ struct DPrimRef { int32_t type, index; };
 // left child of node i is i+1.  count > 0: leaf over prims[a .. a+count); else a = right child.
 template <class R> struct DNode2 { R lo[3], hi[3]; int32_t a, count; };
 
+// Single-precision traversal layout.  One 64-byte record per INNER node holds the boxes of both
+// children (so a traversal step is one 64-byte fetch and the box of a popped node is never
+// re-read); a child code >= 0 is another record, a negative code ~((first << 2) | count) is a
+// leaf over leaf_prims[first .. first+count).  Boxes are rounded outward, except flat ones.
+struct alignas(16) DNodePair { float lo_l[3], hi_l[3], lo_r[3], hi_r[3]; int32_t cl, cr, pad0, pad1; };
+// Leaf-ordered primitive records (48 bytes, three 16-byte fetches): a triangle's vertices in
+// place, or (type != PRIM_TRIANGLE) a reference to a sphere / box tested through its own table.
+struct alignas(16) DLeafPrim { float v0[3]; int32_t mat; float v1[3]; int32_t index; float v2[3]; int32_t type; };
+
 template <class R> struct DEnv {
   const float* texel;        // RGB, row 0 = top
   const R* marginal;         // h+1
@@ -46,8 +55,9 @@ template <class R> struct DScene {
   const DPoint<R>* points; const DQuad<R>* quads; const DDisk<R>* disks; const DMaterial<R>* mats;
   const DImage* images; const int32_t* emissive;   // indices of emissive spheres, ascending
   const DNode2<R>* nodes; const DPrimRef* prims;    // production BVH + primitive order (reference leaf order)
+  const DNodePair* pairs; const DLeafPrim* leaf_prims; // single-precision traversal layout (NULL in the double scene)
   int32_t n_spheres, n_planes, n_tris, n_boxes, n_points, n_quads, n_disks, n_mats, n_images, n_emissive;
-  int32_t n_nodes, n_prims;
+  int32_t n_nodes, n_prims, n_pairs;
   DEnv<R> env;
 };
 

@@ -235,3 +235,36 @@ def test_error_paths(pkg, load_scene):
             pt.render()
     with pytest.raises(abi.RtxError, match="out of range"):
         pkg.renderer.HipPathTracer(1 << 20)
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "kitchen_sink", "textured", "soup"])
+def test_wavefront_pipeline_equals_fused(name, pkg, tracer, load_scene):
+    """The queue-based pipeline runs the same per-path arithmetic in the same sample order as the
+    fused kernel; only instruction selection (multiply-add fusion) may differ between the two
+    compilations, so films agree to single-precision rounding and all counters are equal."""
+    sd = soup_scene(pkg, load_scene) if name == "soup" else load_scene(name)
+    W, H = 80, 45
+    pt = tracer(sd)
+    pt.set_camera(sd.camera(W, H))
+    base = dict(width=W, height=H, samples_per_pixel=12, max_depth=min(sd.max_depth, 30), seed=77)
+    pt.set_settings(sd.settings(pipeline=pkg.abi.PIPELINE_FUSED, **base))
+    a = pt.render().astype(np.float64)
+    sa = pt.last_stats
+    pt.set_settings(sd.settings(pipeline=pkg.abi.PIPELINE_WAVEFRONT, **base))
+    b = pt.render().astype(np.float64)
+    sb = pt.last_stats
+    assert sb.pipeline_used == pkg.abi.PIPELINE_WAVEFRONT and sa.pipeline_used == pkg.abi.PIPELINE_FUSED
+    assert sb.samples == sa.samples == W * H * 12
+    if name == "kitchen_sink":
+        # its checker floor lies in the plane y = 0, where floor(y / scale) flips on the sign of a
+        # rounding residue (see test_f64_film_equals_oracle): only means are comparable
+        assert abs(a.mean() - b.mean()) < 0.015 * a.mean()
+    else:
+        bad = np.abs(a - b) > 1e-3 * (1.0 + np.abs(a))
+        assert bad.mean() < 0.01, (bad.mean(), np.abs(a - b).max())
+        assert abs(a.mean() - b.mean()) < 2e-3 * (1 + a.mean())
+    assert abs(int(sb.rays_closest) - int(sa.rays_closest)) <= 0.002 * sa.rays_closest
+    assert abs(int(sb.rays_shadow) - int(sa.rays_shadow)) <= 0.002 * sa.rays_shadow
+    # the wavefront pipeline is itself reproducible bit for bit
+    c = pt.render().astype(np.float64)
+    assert np.array_equal(b, c)
