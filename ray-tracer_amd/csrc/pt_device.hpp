@@ -1068,10 +1068,16 @@ RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec
     else sdir = refract(ud, rec.n, ratio);
   }
   ps.thr = ps.thr * atten;
-  if (bounce > 3) {  // ref: engine/renderer.cpp:785-790
+  // Russian roulette, ref: engine/renderer.cpp:785-790.  Written without an early return: a
+  // terminated path simply gets flags = 0 (its ray and throughput are never read again).  With
+  // `return` here hipcc 7.2 -O2/-O3 emitted, in one instantiation, code that gave the SURVIVING
+  // lanes the old ray.d.y/z (the copy meant for terminated lanes ran for every lane of the branch).
+  bool killed = false;
+  if (bounce > 3) {
     R p = max_(ps.thr.x, max_(ps.thr.y, ps.thr.z));
-    if (p < R(0.01) || u16lo<R>(rn.z) > p) { ps.bounce_flags = 0; return did; }
-    ps.thr = ps.thr * (R(1) / p);
+    killed = p < R(0.01) || u16lo<R>(rn.z) > p;
+    R boost = killed ? R(1) : R(1) / p;
+    ps.thr = ps.thr * boost;
   }
   ps.ray.o = rec.p;
   ps.ray.d = sdir;
@@ -1079,6 +1085,7 @@ RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec
   const bool next_pending = nee && mis && !(flags & F_SPEC) && bsdf_pdf > R(0);
   if (next_pending) flags |= F_PENDING;
   if (bounce + 1 >= P.max_depth && !next_pending) flags = 0;
+  if (killed) flags = 0;
   ps.bounce_flags = flags ? (((uint32_t)(bounce + 1) << 4) | flags) : 0u;
   return did;
 }

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,7 @@ struct HostScene {
   int upload(const rtx_scene_desc& d, std::string& err);
   // Which intersection mode the integrator kernels use for this scene.
   int fused_mode(bool f64) const {
+    if (const char* e = getenv("RTX_FORCE_MODE")) { int m = atoi(e); if (m == MODE_TREE || m == MODE_TREE_UV) return m; }   // diagnostics only
     const bool spheres_only = dev_f.n_tris == 0 && dev_f.n_boxes == 0 && dev_f.n_spheres <= kFlatMaxSpheres;
     if (!f64 && spheres_only && dev_f.n_images == 0) return MODE_FLAT;
     return dev_f.n_images > 0 ? MODE_TREE_UV : MODE_TREE;

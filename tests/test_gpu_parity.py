@@ -237,11 +237,18 @@ def test_error_paths(pkg, load_scene):
         pkg.renderer.HipPathTracer(1 << 20)
 
 
+@pytest.mark.parametrize("force_mode", [None, "0", "1"])
 @pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "kitchen_sink", "textured", "soup"])
-def test_wavefront_pipeline_equals_fused(name, pkg, tracer, load_scene):
+def test_wavefront_pipeline_equals_fused(name, force_mode, pkg, tracer, load_scene, monkeypatch):
     """The queue-based pipeline runs the same per-path arithmetic in the same sample order as the
     fused kernel; only instruction selection (multiply-add fusion) may differ between the two
-    compilations, so films agree to single-precision rounding and all counters are equal."""
+    compilations, so films agree to single-precision rounding and all counters are equal.
+    RTX_FORCE_MODE (a diagnostic switch of the library) pushes every scene through the tree-walking
+    kernel instances too (0: without, 1: with u/v resolution), whatever the scene would pick."""
+    if force_mode is None:
+        monkeypatch.delenv("RTX_FORCE_MODE", raising=False)
+    else:
+        monkeypatch.setenv("RTX_FORCE_MODE", force_mode)
     sd = soup_scene(pkg, load_scene) if name == "soup" else load_scene(name)
     W, H = 80, 45
     pt = tracer(sd)
@@ -260,8 +267,9 @@ def test_wavefront_pipeline_equals_fused(name, pkg, tracer, load_scene):
         # rounding residue (see test_f64_film_equals_oracle): only means are comparable
         assert abs(a.mean() - b.mean()) < 0.015 * a.mean()
     else:
-        bad = np.abs(a - b) > 1e-3 * (1.0 + np.abs(a))
-        assert bad.mean() < 0.01, (bad.mean(), np.abs(a - b).max())
+        # a rounding difference can flip a grazing intersection for a rare sample: allow a few pixels
+        bad = (np.abs(a - b) > 1e-3 * (1.0 + np.abs(a))).any(axis=2)
+        assert bad.mean() < 0.004, (bad.mean(), np.abs(a - b).max())
         assert abs(a.mean() - b.mean()) < 2e-3 * (1 + a.mean())
     assert abs(int(sb.rays_closest) - int(sa.rays_closest)) <= 0.002 * sa.rays_closest
     assert abs(int(sb.rays_shadow) - int(sa.rays_shadow)) <= 0.002 * sa.rays_shadow
