@@ -316,7 +316,7 @@ template <class R, bool WANT_UV> RTX_DEV void finalize_hit(const DScene<R>& sc, 
 // Per-lane traversal stack in LDS, laid out [level][lane] so a wave's accesses to one level
 // are one conflict-free row.
 struct LaneStack {
-  int* base; int stride;
+  int* base; int stride; int limit;   // limit = levels the kernel's LDS allocation holds
   RTX_DEV int& at(int level) const { return base[level * stride]; }
 };
 
@@ -366,7 +366,7 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
         R er = slab_entry(rr, r, inv, t_min, c.t, ok_r);
         if (ok_l && ok_r) {
           int near = el <= er ? node + 1 : nd.a, far = el <= er ? nd.a : node + 1;
-          if (sp < kStackDepth) st.at(sp++) = far;
+          if (sp < st.limit) st.at(sp++) = far;
           node = near; descend = true;
         } else if (ok_l) { node = node + 1; descend = true; }
         else if (ok_r) { node = nd.a; descend = true; }
@@ -452,7 +452,7 @@ template <bool ANY> RTX_DEV bool walk_pairs(const DScene<float>& sc, const Ray<f
     if (ok_far && e_far < c.t) {
       if (far < 0) { pair_leaf<ANY>(sc, far, r, t_min, c, rank); if (ANY && c.type >= 0) return true; }
       else if (go == 0x7fffffff) go = far;
-      else if (sp < kStackDepth) st.at(sp++) = far;
+      else if (sp < st.limit) st.at(sp++) = far;
     }
     if (go != 0x7fffffff) { node = go; continue; }
     if (sp == 0) break;
@@ -462,6 +462,45 @@ template <bool ANY> RTX_DEV bool walk_pairs(const DScene<float>& sc, const Ray<f
   c.ua = (float)walk_steps; c.uv_kind = 1;
 #endif
   return c.type >= 0;
+}
+
+// The same walk cut into resumable steps, for persistent kernels whose lanes pick up a new ray
+// as soon as theirs is finished.  One step = at most one child-pair fetch followed by at most
+// one leaf, so that all lanes of a wave meet again at the pair fetch and at the leaf test
+// instead of running them in separate divergent branches.  The farther child goes on the
+// stack whether it is an inner node or a leaf; a popped entry is not re-tested against the
+// shrunken interval (its children are, one step later).
+struct PairWalk { V3<float> inv; int node, sp, rank; };
+constexpr int kWalkDone = 0x7fffffff;
+
+RTX_DEV void pair_walk_begin(PairWalk& w, const Ray<float>& r) {
+  w.inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+  w.node = 0; w.sp = 0; w.rank = -1;
+}
+
+template <bool ANY> RTX_DEV void pair_walk_step(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, PairWalk& w, LaneStack st) {
+  if (w.node >= 0 && w.node != kWalkDone) {
+    const DNodePair p = sc.pairs[w.node];
+    float el, er;
+    const bool ok_l = pair_slab(p.lo_l, p.hi_l, r, w.inv, t_min, c.t, el);
+    const bool ok_r = pair_slab(p.lo_r, p.hi_r, r, w.inv, t_min, c.t, er);
+    const bool swap = ok_l && ok_r && er < el;
+    const int near = swap ? p.cr : p.cl, far = swap ? p.cl : p.cr;
+    const bool ok_near = swap ? ok_r : ok_l, ok_far = swap ? ok_l : ok_r;
+    int go = kWalkDone;
+    if (ok_near) go = near;
+    if (ok_far) {
+      if (go == kWalkDone) go = far;
+      else if (w.sp < st.limit) st.at(w.sp++) = far;
+    }
+    if (go == kWalkDone && w.sp > 0) go = st.at(--w.sp);
+    w.node = go;
+  }
+  if (w.node < 0) {
+    pair_leaf<ANY>(sc, w.node, r, t_min, c, w.rank);
+    if (ANY && c.type >= 0) { w.node = kWalkDone; return; }
+    w.node = w.sp > 0 ? st.at(--w.sp) : kWalkDone;
+  }
 }
 
 template <class R, bool ANY> RTX_DEV bool walk_tree(const DScene<R>& sc, const Ray<R>& r, R t_min, Cand<R>& c, LaneStack st) {
@@ -482,16 +521,19 @@ template <class R, bool WANT_UV> RTX_DEV bool closest_hit(const DScene<R>& sc, c
 }
 
 // Visibility: "does Scene::hit return true on [t_min, t_max]" (ref: engine/renderer.cpp:679).
-template <class R> RTX_DEV bool occluded(const DScene<R>& sc, const Ray<R>& r, R t_min, R t_max, LaneStack st) {
-  Cand<R> c;
-  cand_init(c, t_max);
-  if (walk_tree<R, true>(sc, r, t_min, c, st)) return true;
+template <class R> RTX_DEV bool occluded_unbounded(const DScene<R>& sc, const Ray<R>& r, R t_min, R t_max) {
   R t, u, v;
   bool any = false;
   for (int i = 0; i < sc.n_planes; ++i) any |= plane_t(sc.planes[i], r, t_min, t_max, t);
   for (int i = 0; i < sc.n_quads; ++i) any |= quad_t(sc.quads[i], r, t_min, t_max, t, u, v);
   for (int i = 0; i < sc.n_disks; ++i) any |= disk_t(sc.disks[i], r, t_min, t_max, t, u, v);
   return any;
+}
+template <class R> RTX_DEV bool occluded(const DScene<R>& sc, const Ray<R>& r, R t_min, R t_max, LaneStack st) {
+  Cand<R> c;
+  cand_init(c, t_max);
+  if (walk_tree<R, true>(sc, r, t_min, c, st)) return true;
+  return occluded_unbounded(sc, r, t_min, t_max);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -44,6 +44,14 @@ struct HostScene {
     if (!f64 && spheres_only && dev_f.n_images == 0) return MODE_FLAT;
     return dev_f.n_images > 0 ? MODE_TREE_UV : MODE_TREE;
   }
+  // Levels a traversal stack needs: the tree halves the primitive count at every level down to
+  // leaves of at most two, and a walk parks at most one node per level.
+  int stack_levels() const {
+    int levels = 1;
+    for (long long n = n_prims; n > 2; n = (n + 1) / 2) ++levels;
+    levels += 1;
+    return levels < kStackDepth ? levels : kStackDepth;
+  }
   void release();
 };
 
@@ -72,6 +80,6 @@ struct WavefrontPool {
   void release();
 };
 int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* d_film,
-                     DCounters* counters, int n_cus, int mode, bool needs_stack, hipStream_t stream, uint32_t& launches, std::string& err);
+                     DCounters* counters, int n_cus, int mode, int stack_levels, hipStream_t stream, uint32_t& launches, std::string& err);
 
 }  // namespace rtx

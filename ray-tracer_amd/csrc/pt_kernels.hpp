@@ -9,10 +9,11 @@ namespace rtx {
 // Dynamic LDS of a workgroup: [material table (when staged)] [traversal stacks, [level][lane]].
 extern __shared__ int lds_dyn[];
 
-RTX_DEV LaneStack lane_stack(int first_int) {
+RTX_DEV LaneStack lane_stack(int first_int, int limit = kStackDepth) {
   LaneStack st;
   st.base = lds_dyn + first_int + threadIdx.x;
   st.stride = blockDim.x;
+  st.limit = limit;
   return st;
 }
 

@@ -3,10 +3,10 @@
 // A pool of path slots lives in HBM as structure-of-arrays.  One iteration advances every live
 // path by one vertex with three kernels:
 //
-//   wf_generate_extend  slots whose path ended add it to their chunk sum and start the next
-//                       sample (or fetch the next (pixel, chunk) work item); every live slot's ray
-//                       is traced to its closest hit; surviving slots are compacted into the next
-//                       ray queue
+//   wf_generate         slots whose path ended add it to their chunk sum and start the next
+//                       sample (or fetch the next (pixel, chunk) work item); slots that still have
+//                       a ray to trace are compacted into the next ray queue
+//   wf_extend           every queued slot's ray is traced to its closest hit
 //   wf_shade            the vertex is shaded (emission, MIS, light sample, scatter, roulette);
 //                       light samples that need a visibility test are compacted into the
 //                       shadow-ray queue
@@ -39,7 +39,13 @@ struct WfArrays {
   uint32_t n_slots;
 };
 
-struct WfControl { uint32_t n_q[2]; uint32_t n_shadow; uint32_t pad; };
+struct WfControl { uint32_t n_q[2]; uint32_t n_shadow; uint32_t cursor; };   // cursor: next queue entry a persistent kernel hands out
+
+// A persistent traversal wave refills its idle lanes when fewer than this many are walking.
+#ifndef RTX_REFILL_BELOW
+#define RTX_REFILL_BELOW 16
+#endif
+constexpr int kRefillBelow = RTX_REFILL_BELOW;
 
 constexpr int kWfArrays = 6 + 3 + 3 + 3 + 1 + 7 + 3 + 2 + 2 + 1 + 7 + 3;   // 4-byte arrays of n_slots entries
 
@@ -55,39 +61,58 @@ RTX_DEV uint32_t wave_append(uint32_t* counter) {
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// The lanes for which `want` holds take consecutive entries of a queue of n through the shared
+// cursor (one atomic per wave); returns the entry, or 0xffffffff when the queue is used up.
+RTX_DEV uint32_t wave_take(uint32_t* cursor, bool want, uint32_t n) {
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0ull) return 0xffffffffu;
+  const int lane = (int)(threadIdx.x & 63);
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(mask));
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  const uint32_t mine = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  return want && mine < n ? mine : 0xffffffffu;
+}
+
 RTX_DEV void wave_count(unsigned long long* counter, bool pred) {
   const unsigned long long m = __ballot(pred);
   if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1) && m) atomicAdd(counter, (unsigned long long)__popcll(m));
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void wf_generate_extend(DScene<float> sc, DCamera<float> cam, DRenderParams P, WfArrays A, WfControl* ctl,
-                                                             int first, int qin, int qout, float* __restrict__ partial, DCounters* counters) {
+RTX_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+  return v;
+}
+
+// Slots whose path ended add it to their chunk sum and start the next sample (or take the next
+// (pixel, chunk) work item); every slot that still has a ray to trace goes into the next queue.
+__global__ __launch_bounds__(kBlock) void wf_generate(DCamera<float> cam, DRenderParams P, WfArrays A, WfControl* ctl, int first, int qin, int qout,
+                                                      float* __restrict__ partial, DCounters* counters) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = first ? A.n_slots : ctl->n_q[qin];
+  if (i == 0) { ctl->cursor = 0u; ctl->n_shadow = 0u; }   // wf_connect is done with both; wf_extend and the next wf_shade start from zero
   if (i >= n) return;
-  const uint32_t slot = first ? i : A.q[qin][i];
-  uint32_t bf = first ? 0u : A.bflags[slot];
-  Ray<float> ray;
+  const uint32_t sl = first ? i : A.q[qin][i];
+  const uint32_t bf = first ? 0u : A.bflags[sl];
   bool live = true, started = false;
   if (!(bf & F_ALIVE)) {
     const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
     const uint32_t n_items = npix * (uint32_t)P.n_chunks;
-    uint32_t s = first ? 0u : A.sample[slot], s_end = first ? 0u : A.s_end[slot];
+    uint32_t s = first ? 0u : A.sample[sl], s_end = first ? 0u : A.s_end[sl];
     V3<float> sum = {0.f, 0.f, 0.f};
-    if (!first) {
-      sum = {A.sum[0][slot] + A.acc[0][slot], A.sum[1][slot] + A.acc[1][slot], A.sum[2][slot] + A.acc[2][slot]};
-    }
-    uint32_t pixel, xy;
+    if (!first) sum = {A.sum[0][sl] + A.acc[0][sl], A.sum[1][sl] + A.acc[1][sl], A.sum[2][sl] + A.acc[2][sl]};
+    uint32_t pixel = 0, xy = 0;
     if (s == s_end) {
       if (s_end != 0u) {
-        float* o = partial + (size_t)A.cur[slot] * 3u;
+        float* o = partial + (size_t)A.cur[sl] * 3u;
         o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
       }
-      const uint32_t item = first ? i : A.next[slot];
+      const uint32_t item = first ? sl : A.next[sl];
       if (item >= n_items) {
         live = false;
-        A.s_end[slot] = 0u; A.sample[slot] = 0u;
+        A.s_end[sl] = 0u; A.sample[sl] = 0u;
       } else {
         const uint32_t chunk = item / npix;
         const uint32_t pix = item - chunk * npix;
@@ -99,49 +124,87 @@ __global__ __launch_bounds__(kBlock) void wf_generate_extend(DScene<float> sc, D
         s = chunk * (uint32_t)P.chunk_spp;
         s_end = s + (uint32_t)P.chunk_spp < (uint32_t)P.spp ? s + (uint32_t)P.chunk_spp : (uint32_t)P.spp;
         sum = {0.f, 0.f, 0.f};
-        A.cur[slot] = item; A.next[slot] = item + A.n_slots; A.xy[slot] = xy; A.pixel[slot] = pixel; A.s_end[slot] = s_end;
+        A.cur[sl] = item; A.next[sl] = item + A.n_slots; A.xy[sl] = xy; A.pixel[sl] = pixel; A.s_end[sl] = s_end;
       }
     } else {
-      xy = A.xy[slot]; pixel = A.pixel[slot];
+      xy = A.xy[sl]; pixel = A.pixel[sl];
     }
     if (live) {
       PathState<float> ps;
       PathKey key = {pixel, P.seed, s};
       path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key);
-      ray = ps.ray;
-      A.sample[slot] = s + 1u;     // index of the NEXT sample; the current one is sample - 1
-      A.sum[0][slot] = sum.x; A.sum[1][slot] = sum.y; A.sum[2][slot] = sum.z;
-      A.ray[0][slot] = ray.o.x; A.ray[1][slot] = ray.o.y; A.ray[2][slot] = ray.o.z;
-      A.ray[3][slot] = ray.d.x; A.ray[4][slot] = ray.d.y; A.ray[5][slot] = ray.d.z;
-      A.thr[0][slot] = 1.f; A.thr[1][slot] = 1.f; A.thr[2][slot] = 1.f;
-      A.acc[0][slot] = 0.f; A.acc[1][slot] = 0.f; A.acc[2][slot] = 0.f;
-      A.bsdf_pdf[slot] = 0.f;
-      A.bflags[slot] = F_ALIVE;
+      A.sample[sl] = s + 1u;     // index of the NEXT sample; the current one is sample - 1
+      A.sum[0][sl] = sum.x; A.sum[1][sl] = sum.y; A.sum[2][sl] = sum.z;
+      A.ray[0][sl] = ps.ray.o.x; A.ray[1][sl] = ps.ray.o.y; A.ray[2][sl] = ps.ray.o.z;
+      A.ray[3][sl] = ps.ray.d.x; A.ray[4][sl] = ps.ray.d.y; A.ray[5][sl] = ps.ray.d.z;
+      A.thr[0][sl] = 1.f; A.thr[1][sl] = 1.f; A.thr[2][sl] = 1.f;
+      A.acc[0][sl] = 0.f; A.acc[1][sl] = 0.f; A.acc[2][sl] = 0.f;
+      A.bsdf_pdf[sl] = 0.f;
+      A.bflags[sl] = F_ALIVE;
       started = true;
     }
-  } else {
-    ray.o = {A.ray[0][slot], A.ray[1][slot], A.ray[2][slot]};
-    ray.d = {A.ray[3][slot], A.ray[4][slot], A.ray[5][slot]};
   }
-  if (live) {
-    int id = -1, uv = 0;
-    float t = 0.f, ua = 0.f, ub = 0.f;
-    if constexpr (MODE == MODE_FLAT) {
-      Hit<float> h;   // flat scenes: the candidate is cheap to redo in the shade kernel; keep t + id
-      if (flat_closest(sc, ray, 0.001f, 1e9f, h)) { id = (h.type << 24) | h.idx; t = h.t; }
-    } else {
-      Cand<float> c;
-      cand_init(c, 1e9f);
-      walk_tree<float, false>(sc, ray, 0.001f, c, lane_stack(0));
-      test_unbounded(sc, ray, 0.001f, c);
-      if (c.type >= 0) { id = (c.type << 24) | c.idx; t = c.t; ua = c.ua; ub = c.ub; uv = (c.uv_kind << 24) | (c.uv_idx & 0xffffff); }
-    }
-    A.hit_t[slot] = t; A.hit_id[slot] = id;
-    if constexpr (MODE == MODE_TREE_UV) { A.hit_ua[slot] = ua; A.hit_ub[slot] = ub; A.hit_uv[slot] = uv; }
-    A.q[qout][wave_append(&ctl->n_q[qout])] = slot;
-  }
+  if (live) A.q[qout][wave_append(&ctl->n_q[qout])] = sl;
   wave_count(&counters->closest, live);
   wave_count(&counters->samples, started);
+}
+
+// Both traversal kernels are persistent: a launch holds as many lanes as the chip keeps
+// resident, every lane walks one ray at a time in resumable steps and takes its next queue
+// entry (grid-stride) when its ray is finished, so a wave is not held back by its longest
+// walk.  A wave leaves when none of its lanes has a ray and none can get one.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int q, int stack_levels) {
+  const uint32_t n = ctl->n_q[q];
+  bool more = true;   // wave-uniform: the queue may still have entries
+  const LaneStack st = lane_stack(0, stack_levels);
+  const bool tree = MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims;
+  uint32_t slot = 0;
+  Ray<float> ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
+  Cand<float> c;
+  PairWalk w;
+  cand_init(c, 1e9f);
+  w.node = kWalkDone; w.sp = 0; w.rank = -1; w.inv = {0.f, 0.f, 0.f};
+  int state = 0;   // 0 no ray, 1 walking, 2 walk finished, result not yet stored
+  for (;;) {
+    // Refill in batches: finished lanes wait until enough of the wave is idle, then store their
+    // hits and fetch together.
+    if (__popcll(__ballot(state == 1)) < kRefillBelow) {
+      if (state == 2) {
+        int id = -1, uv = 0;
+        float t = 0.f, ua = 0.f, ub = 0.f;
+        if constexpr (MODE == MODE_FLAT) {
+          Hit<float> h;   // flat scenes: the candidate is cheap to redo in the shade kernel; keep t + id
+          if (flat_closest(sc, ray, 0.001f, 1e9f, h)) { id = (h.type << 24) | h.idx; t = h.t; }
+        } else {
+          test_unbounded(sc, ray, 0.001f, c);
+          if (c.type >= 0) { id = (c.type << 24) | c.idx; t = c.t; ua = c.ua; ub = c.ub; uv = (c.uv_kind << 24) | (c.uv_idx & 0xffffff); }
+        }
+        A.hit_t[slot] = t; A.hit_id[slot] = id;
+        if constexpr (MODE == MODE_TREE_UV) { A.hit_ua[slot] = ua; A.hit_ub[slot] = ub; A.hit_uv[slot] = uv; }
+        state = 0;
+      }
+      const uint32_t e = more ? wave_take(&ctl->cursor, state == 0, n) : 0xffffffffu;
+      more = __ballot(e != 0xffffffffu) != 0ull;
+      if (e != 0xffffffffu) {
+        slot = A.q[q][e];
+        ray.o = {A.ray[0][slot], A.ray[1][slot], A.ray[2][slot]};
+        ray.d = {A.ray[3][slot], A.ray[4][slot], A.ray[5][slot]};
+        cand_init(c, 1e9f);
+        if (tree) pair_walk_begin(w, ray);
+        state = 1;
+      }
+      if (__ballot(state == 1) == 0ull) break;
+    }
+    if (state == 1) {
+      bool done = true;
+      if constexpr (MODE != MODE_FLAT) {
+        if (tree) { pair_walk_step<false>(sc, ray, 0.001f, c, w, st); done = w.node == kWalkDone; }
+        else walk_bounded<float, false>(sc, ray, 0.001f, c, st);
+      }
+      if (done) state = 2;
+    }
+  }
 }
 
 // Rebuild the Hit of a stored candidate (point, normal, face, material, u/v).
@@ -165,6 +228,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene<float> sc, DRenderPara
   const DMaterial<float>* mats = sc.mats;
   if constexpr (LDS_MATS) mats = stage_materials(sc);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { ctl->cursor = 0u; ctl->n_q[1 - q] = 0u; }   // wf_extend is done with the cursor; the next wf_generate fills the other queue
   if (i >= ctl->n_q[q]) return;
   const uint32_t slot = A.q[q][i];
   PathState<float> ps;
@@ -195,42 +259,92 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene<float> sc, DRenderPara
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays A, const WfControl* ctl) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ctl->n_shadow) return;
-  Ray<float> sr;
-  sr.o = {A.sh[0][i], A.sh[1][i], A.sh[2][i]};
-  sr.d = {A.sh[3][i], A.sh[4][i], A.sh[5][i]};
-  const float t_max = A.sh[6][i];
-  if (!trace_occluded<float, MODE>(sc, sr, 0.001f, t_max, lane_stack(0))) {
-    const uint32_t slot = A.sh_slot[i];   // at most one shadow ray per slot per iteration: no atomics needed
-    A.acc[0][slot] += A.sh_c[0][i]; A.acc[1][slot] += A.sh_c[1][i]; A.acc[2][slot] += A.sh_c[2][i];
+__global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int stack_levels) {
+  const uint32_t n = ctl->n_shadow;
+  bool more = true;   // wave-uniform: the queue may still have entries
+  const LaneStack st = lane_stack(0, stack_levels);
+  const bool tree = MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims;
+  uint32_t i = 0;
+  float t_max = 0.f;
+  Ray<float> sr = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
+  Cand<float> c;
+  PairWalk w;
+  cand_init(c, 1e9f);
+  w.node = kWalkDone; w.sp = 0; w.rank = -1; w.inv = {0.f, 0.f, 0.f};
+  int state = 0;   // 0 no ray, 1 walking, 2 finished (occluded), 3 finished (visible)
+  for (;;) {
+    if (__popcll(__ballot(state == 1)) < kRefillBelow) {
+      if (state == 3) {
+        const uint32_t slot = A.sh_slot[i];   // at most one shadow ray per slot per iteration: no atomics needed
+        A.acc[0][slot] += A.sh_c[0][i]; A.acc[1][slot] += A.sh_c[1][i]; A.acc[2][slot] += A.sh_c[2][i];
+      }
+      if (state != 1) state = 0;
+      {
+        const uint32_t e = more ? wave_take(&ctl->cursor, state == 0, n) : 0xffffffffu;
+        more = __ballot(e != 0xffffffffu) != 0ull;
+        if (e != 0xffffffffu) {
+          i = e;
+          sr.o = {A.sh[0][i], A.sh[1][i], A.sh[2][i]};
+          sr.d = {A.sh[3][i], A.sh[4][i], A.sh[5][i]};
+          t_max = A.sh[6][i];
+          cand_init(c, t_max);
+          if (tree) pair_walk_begin(w, sr);
+          state = 1;
+        }
+      }
+      if (__ballot(state == 1) == 0ull) break;
+    }
+    if (state == 1) {
+      bool done = true, hit;
+      if constexpr (MODE == MODE_FLAT) hit = flat_occluded(sc, sr, 0.001f, t_max);
+      else if (tree) {
+        pair_walk_step<true>(sc, sr, 0.001f, c, w, st);
+        done = w.node == kWalkDone;
+        hit = c.type >= 0;
+        if (done && !hit) hit = occluded_unbounded(sc, sr, 0.001f, t_max);
+      } else hit = occluded(sc, sr, 0.001f, t_max, st);
+      if (done) state = hit ? 2 : 3;
+    }
   }
 }
 
 template <int MODE> void launch_iteration_kernels(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, const WfArrays& A, WfControl* ctl,
-                                                  float* partial, DCounters* counters, bool lds_mats, size_t mat_lds, size_t stack_lds, unsigned grid,
-                                                  int step /*0 first generate, 1 shade, 2 connect, 3 generate*/, int qa, int qb, hipStream_t stream) {
+                                                  float* partial, DCounters* counters, bool lds_mats, size_t mat_lds, int stack_levels, unsigned grid,
+                                                  unsigned resident_blocks, int step /*0 first generate, 1 shade, 2 connect, 3 generate*/, int qa, int qb,
+                                                  hipStream_t stream, uint32_t& launches) {
   const dim3 g(grid), b(kBlock);
-  const size_t walk_lds = MODE == MODE_FLAT ? 0 : stack_lds;
-  if (step == 0 || step == 3)
-    hipLaunchKernelGGL((wf_generate_extend<MODE>), g, b, walk_lds, stream, sc, cam, P, A, ctl, step == 0 ? 1 : 0, qa, qb, partial, counters);
-  else if (step == 1) {
+  const dim3 gw(grid < resident_blocks ? grid : resident_blocks);   // persistent traversal kernels
+  const size_t walk_lds = MODE == MODE_FLAT ? 0 : (size_t)stack_levels * kBlock * sizeof(int);
+  if (step == 0 || step == 3) {
+    hipLaunchKernelGGL(wf_generate, g, b, 0, stream, cam, P, A, ctl, step == 0 ? 1 : 0, qa, qb, partial, counters);
+    hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, qb, stack_levels);
+    ++launches;
+  } else if (step == 1) {
     if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, b, mat_lds, stream, sc, P, A, ctl, qa, counters);
     else hipLaunchKernelGGL((wf_shade<MODE, false>), g, b, 0, stream, sc, P, A, ctl, qa, counters);
   } else
-    hipLaunchKernelGGL((wf_connect<MODE>), g, b, walk_lds, stream, sc, A, ctl);
+    hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, stack_levels);
+}
+
+// Blocks of the traversal kernels one CU keeps resident (the smaller of the two kernels' figures).
+template <int MODE> int walk_blocks_per_cu(int stack_levels) {
+  const size_t walk_lds = MODE == MODE_FLAT ? 0 : (size_t)stack_levels * kBlock * sizeof(int);
+  int a = 0, b = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, wf_extend<MODE>, kBlock, walk_lds) != hipSuccess) a = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, wf_connect<MODE>, kBlock, walk_lds) != hipSuccess) b = 0;
+  const int nb = a < b ? a : b;
+  return nb > 0 ? nb : 2;
 }
 
 }  // namespace
 
 int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* d_film,
-                     DCounters* counters, int n_cus, int mode, bool needs_stack, hipStream_t stream, uint32_t& launches, std::string& err) {
+                     DCounters* counters, int n_cus, int mode, int stack_levels, hipStream_t stream, uint32_t& launches, std::string& err) {
   const unsigned long long npix = (unsigned long long)P.rows * P.width;
   const unsigned long long items = npix * (unsigned long long)P.n_chunks;
   if (items >= 0x7fffffffull) { err = "film too large for one launch"; return RTX_ERR_INVALID_ARGUMENT; }
   // Pool size: enough slots to keep every CU at full occupancy several times over.
-  const uint32_t n_slots = (uint32_t)std::min<unsigned long long>(items, (unsigned long long)n_cus * 2048ull * 8ull);
+  const uint32_t n_slots = (uint32_t)std::min<unsigned long long>(items, (unsigned long long)n_cus * 2048ull * 32ull);
   if (!pool.state.ensure((size_t)kWfArrays * n_slots * 4) || !pool.control.ensure(sizeof(WfControl)) ||
       !pool.queues.ensure((size_t)items * 3 * sizeof(float))) { err = "pool allocation"; return RTX_ERR_OUT_OF_MEMORY; }
   WfArrays A;
@@ -259,13 +373,15 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   const size_t mat_bytes = (size_t)sc.n_mats * sizeof(DMaterial<float>);
   const bool lds_mats = mat_bytes <= kMaxLdsMaterialBytes;
   const size_t mat_lds = (mat_bytes + 15) & ~(size_t)15;
-  const size_t stack_lds = needs_stack ? (size_t)kStackDepth * kBlock * sizeof(int) : 0;
   if (!lds_mats) mode = MODE_TREE_UV;
+  const int per_cu = mode == MODE_FLAT ? walk_blocks_per_cu<MODE_FLAT>(stack_levels) : mode == MODE_TREE ? walk_blocks_per_cu<MODE_TREE>(stack_levels)
+                                                                                                       : walk_blocks_per_cu<MODE_TREE_UV>(stack_levels);
+  const unsigned resident = (unsigned)n_cus * (unsigned)per_cu;
 
   auto run = [&](int step, int qa, int qb, unsigned grid) {
-    if (mode == MODE_FLAT) launch_iteration_kernels<MODE_FLAT>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_lds, grid, step, qa, qb, stream);
-    else if (mode == MODE_TREE) launch_iteration_kernels<MODE_TREE>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_lds, grid, step, qa, qb, stream);
-    else launch_iteration_kernels<MODE_TREE_UV>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_lds, grid, step, qa, qb, stream);
+    if (mode == MODE_FLAT) launch_iteration_kernels<MODE_FLAT>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches);
+    else if (mode == MODE_TREE) launch_iteration_kernels<MODE_TREE>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches);
+    else launch_iteration_kernels<MODE_TREE_UV>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches);
     ++launches;
   };
   if (hipMemsetAsync(ctl, 0, sizeof(WfControl), stream) != hipSuccess) { err = "memset"; return RTX_ERR_HIP; }
@@ -276,9 +392,6 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   for (unsigned iter = 0;; ++iter) {
     run(1, cur, 0, grid);
     run(2, 0, 0, grid);
-    // clear the queue the next generate/extend fills and the shadow queue
-    if (hipMemsetAsync(&ctl->n_q[1 - cur], 0, sizeof(uint32_t), stream) != hipSuccess ||
-        hipMemsetAsync(&ctl->n_shadow, 0, sizeof(uint32_t), stream) != hipSuccess) { err = "memset"; return RTX_ERR_HIP; }
     run(3, cur, 1 - cur, grid);
     cur = 1 - cur;
     if ((iter & 7u) == 7u || live_bound < 65536u) {
