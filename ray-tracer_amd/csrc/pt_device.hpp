@@ -317,7 +317,18 @@ template <class R, bool WANT_UV> RTX_DEV void finalize_hit(const DScene<R>& sc, 
 // are one conflict-free row.
 struct LaneStack {
   int* base; int stride; int limit;   // limit = levels the kernel's LDS allocation holds
+  int* spill; int spill_stride;       // optional overflow levels in global memory, [level][lane of the grid]
   RTX_DEV int& at(int level) const { return base[level * stride]; }
+  // push / pop with overflow into `spill` (the four-wide walk: the LDS part covers the usual
+  // height, the worst case is three parked children per level)
+  RTX_DEV void push(int& sp, int v) const {
+    if (sp < limit) base[sp * stride] = v; else spill[(size_t)(sp - limit) * spill_stride] = v;
+    ++sp;
+  }
+  RTX_DEV int pop(int& sp) const {
+    --sp;
+    return sp < limit ? base[sp * stride] : spill[(size_t)(sp - limit) * spill_stride];
+  }
 };
 
 template <class R> RTX_DEV R slab_entry(const DNode2<R>& nd, const Ray<R>& r, V3<R> inv, R t_min, R t_max, bool& ok) {
@@ -465,11 +476,13 @@ template <bool ANY> RTX_DEV bool walk_pairs(const DScene<float>& sc, const Ray<f
 }
 
 // The same walk cut into resumable steps, for persistent kernels whose lanes pick up a new ray
-// as soon as theirs is finished.  One step = at most one child-pair fetch followed by at most
-// one leaf, so that all lanes of a wave meet again at the pair fetch and at the leaf test
-// instead of running them in separate divergent branches.  The farther child goes on the
-// stack whether it is an inner node or a leaf; a popped entry is not re-tested against the
-// shrunken interval (its children are, one step later).
+// when theirs is finished.  w.node is an inner pair (>= 0), a leaf code (< 0) or kWalkDone.
+// pair_walk_inner fetches one child pair; pair_walk_leaf tests ONE primitive of the leaf, so
+// every lane of a wave that is in the same phase executes the same instructions.  The kernels
+// run the leaf phase only when enough lanes have a leaf pending (it is the longer of the two
+// and would otherwise run for a handful of lanes on every trip).  The farther child goes on
+// the stack whether it is an inner node or a leaf; a popped entry is not re-tested against the
+// shrunken interval (its children / primitives are).
 struct PairWalk { V3<float> inv; int node, sp, rank; };
 constexpr int kWalkDone = 0x7fffffff;
 
@@ -477,30 +490,46 @@ RTX_DEV void pair_walk_begin(PairWalk& w, const Ray<float>& r) {
   w.inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
   w.node = 0; w.sp = 0; w.rank = -1;
 }
+RTX_DEV bool pair_walk_at_inner(const PairWalk& w) { return w.node >= 0 && w.node != kWalkDone; }
+RTX_DEV bool pair_walk_at_leaf(const PairWalk& w) { return w.node < 0; }
 
-template <bool ANY> RTX_DEV void pair_walk_step(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, PairWalk& w, LaneStack st) {
-  if (w.node >= 0 && w.node != kWalkDone) {
-    const DNodePair p = sc.pairs[w.node];
-    float el, er;
-    const bool ok_l = pair_slab(p.lo_l, p.hi_l, r, w.inv, t_min, c.t, el);
-    const bool ok_r = pair_slab(p.lo_r, p.hi_r, r, w.inv, t_min, c.t, er);
-    const bool swap = ok_l && ok_r && er < el;
-    const int near = swap ? p.cr : p.cl, far = swap ? p.cl : p.cr;
-    const bool ok_near = swap ? ok_r : ok_l, ok_far = swap ? ok_l : ok_r;
-    int go = kWalkDone;
-    if (ok_near) go = near;
-    if (ok_far) {
-      if (go == kWalkDone) go = far;
-      else if (w.sp < st.limit) st.at(w.sp++) = far;
-    }
-    if (go == kWalkDone && w.sp > 0) go = st.at(--w.sp);
-    w.node = go;
+// One four-wide record: test the (up to) four boxes, continue with the nearest child that was
+// entered and park the others on the stack, farthest first.
+RTX_DEV void pair_walk_inner(const DScene<float>& sc, const Ray<float>& r, float t_min, const Cand<float>& c, PairWalk& w, LaneStack st) {
+  const DNodeWide q = sc.wide[w.node];
+  float e[4]; int ch[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float t0 = (q.lo_x[k] - r.o.x) * w.inv.x, t1 = (q.hi_x[k] - r.o.x) * w.inv.x;
+    float a = fminf(t0, t1), b = fmaxf(t0, t1);
+    t0 = (q.lo_y[k] - r.o.y) * w.inv.y; t1 = (q.hi_y[k] - r.o.y) * w.inv.y;
+    a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
+    t0 = (q.lo_z[k] - r.o.z) * w.inv.z; t1 = (q.hi_z[k] - r.o.z) * w.inv.z;
+    a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
+    a = fmaxf(a, t_min); b = fminf(b, c.t);
+    const bool ok = a < b && q.child[k] != kWideEmpty;
+    e[k] = ok ? a : 3.0e38f;
+    ch[k] = ok ? q.child[k] : kWalkDone;
   }
-  if (w.node < 0) {
-    pair_leaf<ANY>(sc, w.node, r, t_min, c, w.rank);
-    if (ANY && c.type >= 0) { w.node = kWalkDone; return; }
-    w.node = w.sp > 0 ? st.at(--w.sp) : kWalkDone;
-  }
+  // sorting network on (entry distance, child): ascending
+#define RTX_CSWAP(i, j) { const bool s_ = e[j] < e[i]; const float te = s_ ? e[j] : e[i]; const float tf = s_ ? e[i] : e[j]; \
+                          const int tc = s_ ? ch[j] : ch[i]; const int td = s_ ? ch[i] : ch[j]; e[i] = te; e[j] = tf; ch[i] = tc; ch[j] = td; }
+  RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+  if (ch[3] != kWalkDone) st.push(w.sp, ch[3]);
+  if (ch[2] != kWalkDone) st.push(w.sp, ch[2]);
+  if (ch[1] != kWalkDone) st.push(w.sp, ch[1]);
+  int go = ch[0];
+  if (go == kWalkDone && w.sp > 0) go = st.pop(w.sp);
+  w.node = go;
+}
+
+template <bool ANY> RTX_DEV void pair_walk_leaf(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, PairWalk& w, LaneStack st) {
+  const int first = (~w.node) >> 2, count = (~w.node) & 3;
+  pair_leaf<ANY>(sc, ~((first << 2) | 1), r, t_min, c, w.rank);
+  if (ANY && c.type >= 0) { w.node = kWalkDone; return; }
+  if (count > 1) w.node = ~(((first + 1) << 2) | (count - 1));
+  else w.node = w.sp > 0 ? st.pop(w.sp) : kWalkDone;
 }
 
 template <class R, bool ANY> RTX_DEV bool walk_tree(const DScene<R>& sc, const Ray<R>& r, R t_min, Cand<R>& c, LaneStack st) {

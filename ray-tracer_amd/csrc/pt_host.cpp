@@ -28,7 +28,7 @@ void DeviceBuffer::release() {
   if (ptr) (void)hipFree(ptr);
   ptr = nullptr; cap = 0;
 }
-void WavefrontPool::release() { state.release(); queues.release(); control.release(); }
+void WavefrontPool::release() { state.release(); queues.release(); control.release(); spill.release(); }
 
 // ------------------------------------------------------------------------------------------
 // Reference-order BVH.  Median split on the longest centroid axis with std::nth_element,
@@ -207,6 +207,48 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
       }
     }
     sc.pairs = push(pool, pairs, ok); sc.leaf_prims = push(pool, leaf, ok); sc.n_pairs = np;
+    // four-wide records: an inner node's children, each replaced by ITS children when it is inner
+    std::vector<int32_t> wide_of(bvh.nodes.size(), -1);
+    std::vector<int32_t> wide_nodes;   // binary node of every wide record, in creation order
+    {
+      std::vector<int32_t> todo{0};
+      wide_of[0] = 0; wide_nodes.push_back(0);
+      for (size_t head = 0; head < wide_nodes.size(); ++head) {
+        const DNodeRef& n = bvh.nodes[(size_t)wide_nodes[head]];
+        const int32_t kids[2] = {n.left, n.right};
+        for (int32_t k : kids) {
+          const DNodeRef& c = bvh.nodes[(size_t)k];
+          if (c.count > 0) continue;
+          const int32_t grand[2] = {c.left, c.right};
+          for (int32_t g : grand)
+            if (bvh.nodes[(size_t)g].count == 0) { wide_of[(size_t)g] = (int32_t)wide_nodes.size(); wide_nodes.push_back(g); }
+        }
+      }
+    }
+    std::vector<DNodeWide> wide(wide_nodes.size());
+    for (size_t w = 0; w < wide_nodes.size(); ++w) {
+      DNodeWide& q = wide[w];
+      memset(&q, 0, sizeof q);
+      for (int k = 0; k < 4; ++k) q.child[k] = kWideEmpty;
+      int used = 0;
+      auto add = [&](int32_t node) {
+        const DNodeRef& c = bvh.nodes[(size_t)node];
+        float lo[3], hi[3];
+        box(node, lo, hi);
+        q.lo_x[used] = lo[0]; q.lo_y[used] = lo[1]; q.lo_z[used] = lo[2];
+        q.hi_x[used] = hi[0]; q.hi_y[used] = hi[1]; q.hi_z[used] = hi[2];
+        q.child[used] = c.count > 0 ? ~((c.first << 2) | c.count) : wide_of[(size_t)node];
+        ++used;
+      };
+      const DNodeRef& n = bvh.nodes[(size_t)wide_nodes[w]];
+      const int32_t kids[2] = {n.left, n.right};
+      for (int32_t k : kids) {
+        const DNodeRef& c = bvh.nodes[(size_t)k];
+        if (c.count > 0) add(k);
+        else { add(c.left); add(c.right); }
+      }
+    }
+    sc.wide = push(pool, wide, ok); sc.n_wide = (int32_t)wide.size();
   }
   sc.spheres = push(pool, sph, ok); sc.planes = push(pool, pls, ok); sc.tris = push(pool, tris, ok); sc.boxes = push(pool, boxes, ok);
   sc.points = push(pool, pts, ok); sc.quads = push(pool, quads, ok); sc.disks = push(pool, disks, ok); sc.mats = push(pool, mats, ok);

@@ -44,14 +44,6 @@ struct HostScene {
     if (!f64 && spheres_only && dev_f.n_images == 0) return MODE_FLAT;
     return dev_f.n_images > 0 ? MODE_TREE_UV : MODE_TREE;
   }
-  // Levels a traversal stack needs: the tree halves the primitive count at every level down to
-  // leaves of at most two, and a walk parks at most one node per level.
-  int stack_levels() const {
-    int levels = 1;
-    for (long long n = n_prims; n > 2; n = (n + 1) / 2) ++levels;
-    levels += 1;
-    return levels < kStackDepth ? levels : kStackDepth;
-  }
   void release();
 };
 
@@ -76,7 +68,7 @@ void launch_selftest(float* out, int n, hipStream_t stream);
 
 // Wavefront pipeline (wavefront.hip): queue storage + the per-iteration launch loop.
 struct WavefrontPool {
-  DeviceBuffer state, queues, control;
+  DeviceBuffer state, queues, control, spill;
   void release();
 };
 int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* d_film,

@@ -14,6 +14,7 @@ RTX_DEV LaneStack lane_stack(int first_int, int limit = kStackDepth) {
   st.base = lds_dyn + first_int + threadIdx.x;
   st.stride = blockDim.x;
   st.limit = limit;
+  st.spill = nullptr; st.spill_stride = 0;
   return st;
 }
 

@@ -37,6 +37,14 @@ template <class R> struct DNode2 { R lo[3], hi[3]; int32_t a, count; };
 // re-read); a child code >= 0 is another record, a negative code ~((first << 2) | count) is a
 // leaf over leaf_prims[first .. first+count).  Boxes are rounded outward, except flat ones.
 struct alignas(16) DNodePair { float lo_l[3], hi_l[3], lo_r[3], hi_r[3]; int32_t cl, cr, pad0, pad1; };
+// Four-wide form of the same tree for the queue-based traversal kernels, whose speed is set
+// by the number of dependent fetches per ray: every other level of the binary tree is folded
+// away, so a record (128 bytes, two cache lines) holds the boxes of up to four grandchildren,
+// component-wise.  child[k]: >= 0 another record, < 0 a leaf code as above, kWideEmpty = unused.
+struct alignas(16) DNodeWide { float lo_x[4], lo_y[4], lo_z[4], hi_x[4], hi_y[4], hi_z[4]; int32_t child[4]; int32_t pad[4]; };
+constexpr int32_t kWideEmpty = 0x7ffffffe;
+// Levels of a four-wide walk's stack kept in LDS; deeper levels (rare) spill to global memory.
+constexpr int kWalkLdsLevels = 12;
 // Leaf-ordered primitive records (48 bytes, three 16-byte fetches): a triangle's vertices in
 // place, or (type != PRIM_TRIANGLE) a reference to a sphere / box tested through its own table.
 struct alignas(16) DLeafPrim { float v0[3]; int32_t mat; float v1[3]; int32_t index; float v2[3]; int32_t type; };
@@ -56,8 +64,9 @@ template <class R> struct DScene {
   const DImage* images; const int32_t* emissive;   // indices of emissive spheres, ascending
   const DNode2<R>* nodes; const DPrimRef* prims;    // production BVH + primitive order (reference leaf order)
   const DNodePair* pairs; const DLeafPrim* leaf_prims; // single-precision traversal layout (NULL in the double scene)
+  const DNodeWide* wide;
   int32_t n_spheres, n_planes, n_tris, n_boxes, n_points, n_quads, n_disks, n_mats, n_images, n_emissive;
-  int32_t n_nodes, n_prims, n_pairs;
+  int32_t n_nodes, n_prims, n_pairs, n_wide;
   DEnv<R> env;
 };
 

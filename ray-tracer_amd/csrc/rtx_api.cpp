@@ -229,7 +229,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     st.kernel_launches = 2;
   } else {
     std::string err;
-    int rc = wavefront_render(c->wf, c->scene.dev_f, c->cam_f, P, d_film, (DCounters*)c->counters.ptr, c->n_cus, c->scene.fused_mode(false), needs_stack ? c->scene.stack_levels() : 0, stream, st.kernel_launches, err);
+    int rc = wavefront_render(c->wf, c->scene.dev_f, c->cam_f, P, d_film, (DCounters*)c->counters.ptr, c->n_cus, c->scene.fused_mode(false), needs_stack ? kWalkLdsLevels : 0, stream, st.kernel_launches, err);
     if (rc != RTX_OK) return fail(rc, "wavefront: %s", err.c_str());
     HIP_TRY(hipEventRecord(c->evm, stream));
   }

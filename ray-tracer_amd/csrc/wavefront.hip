@@ -43,9 +43,14 @@ struct WfControl { uint32_t n_q[2]; uint32_t n_shadow; uint32_t cursor; };   // 
 
 // A persistent traversal wave refills its idle lanes when fewer than this many are walking.
 #ifndef RTX_REFILL_BELOW
-#define RTX_REFILL_BELOW 16
+#define RTX_REFILL_BELOW 40
 #endif
 constexpr int kRefillBelow = RTX_REFILL_BELOW;
+// ... and runs the leaf phase when at least this many lanes have a leaf pending.
+#ifndef RTX_LEAF_BATCH
+#define RTX_LEAF_BATCH 8
+#endif
+constexpr int kLeafBatch = RTX_LEAF_BATCH;
 
 constexpr int kWfArrays = 6 + 3 + 3 + 3 + 1 + 7 + 3 + 2 + 2 + 1 + 7 + 3;   // 4-byte arrays of n_slots entries
 
@@ -75,15 +80,45 @@ RTX_DEV uint32_t wave_take(uint32_t* cursor, bool want, uint32_t n) {
   return want && mine < n ? mine : 0xffffffffu;
 }
 
-RTX_DEV void wave_count(unsigned long long* counter, bool pred) {
-  const unsigned long long m = __ballot(pred);
-  if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1) && m) atomicAdd(counter, (unsigned long long)__popcll(m));
+// Workgroup-level forms for kernels whose every thread reaches the call (they synchronise the
+// workgroup): ONE atomic per workgroup.  A single hot counter takes a few nanoseconds per
+// atomic at the L2, which at one atomic per wave was most of these kernels' run time.
+struct BlockScratch { uint32_t cnt[kBlock / 64]; uint32_t base; uint32_t sum[2]; };
+
+// Entry of the queue for each thread with `want` (0xffffffff for the others).
+RTX_DEV uint32_t block_append(BlockScratch& bs, uint32_t* counter, bool want) {
+  const unsigned long long mask = __ballot(want);
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  __syncthreads();   // a previous use of bs is over
+  if (lane == 0) bs.cnt[wave] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (int k = 0; k < kBlock / 64; ++k) total += bs.cnt[k];
+    bs.base = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t at = bs.base;
+  for (int k = 0; k < wave; ++k) at += bs.cnt[k];
+  at += (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  return want ? at : 0xffffffffu;
 }
 
-RTX_DEV uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
-  return v;
+// counter_a += threads with pa, counter_b += threads with pb.
+RTX_DEV void block_count2(BlockScratch& bs, unsigned long long* counter_a, bool pa, unsigned long long* counter_b, bool pb) {
+  const unsigned long long ma = __ballot(pa), mb = __ballot(pb);
+  __syncthreads();
+  if (threadIdx.x == 0) { bs.sum[0] = 0u; bs.sum[1] = 0u; }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    if (ma) atomicAdd(&bs.sum[0], (uint32_t)__popcll(ma));
+    if (mb) atomicAdd(&bs.sum[1], (uint32_t)__popcll(mb));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (bs.sum[0]) atomicAdd(counter_a, (unsigned long long)bs.sum[0]);
+    if (bs.sum[1]) atomicAdd(counter_b, (unsigned long long)bs.sum[1]);
+  }
 }
 
 // Slots whose path ended add it to their chunk sum and start the next sample (or take the next
@@ -92,12 +127,13 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DCamera<float> cam, DRende
                                                       float* __restrict__ partial, DCounters* counters) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = first ? A.n_slots : ctl->n_q[qin];
+  __shared__ BlockScratch bs;
   if (i == 0) { ctl->cursor = 0u; ctl->n_shadow = 0u; }   // wf_connect is done with both; wf_extend and the next wf_shade start from zero
-  if (i >= n) return;
-  const uint32_t sl = first ? i : A.q[qin][i];
-  const uint32_t bf = first ? 0u : A.bflags[sl];
-  bool live = true, started = false;
-  if (!(bf & F_ALIVE)) {
+  const bool valid = i < n;
+  const uint32_t sl = !valid ? 0u : first ? i : A.q[qin][i];
+  const uint32_t bf = (first || !valid) ? 0u : A.bflags[sl];
+  bool live = valid, started = false;
+  if (valid && !(bf & F_ALIVE)) {
     const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
     const uint32_t n_items = npix * (uint32_t)P.n_chunks;
     uint32_t s = first ? 0u : A.sample[sl], s_end = first ? 0u : A.s_end[sl];
@@ -144,20 +180,25 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DCamera<float> cam, DRende
       started = true;
     }
   }
-  if (live) A.q[qout][wave_append(&ctl->n_q[qout])] = sl;
-  wave_count(&counters->closest, live);
-  wave_count(&counters->samples, started);
+  const uint32_t at = block_append(bs, &ctl->n_q[qout], live);
+  if (live) A.q[qout][at] = sl;
+  block_count2(bs, &counters->closest, live, &counters->samples, started);
 }
 
 // Both traversal kernels are persistent: a launch holds as many lanes as the chip keeps
 // resident, every lane walks one ray at a time in resumable steps and takes its next queue
 // entry (grid-stride) when its ray is finished, so a wave is not held back by its longest
 // walk.  A wave leaves when none of its lanes has a ray and none can get one.
+#ifdef RTX_WALK_STATS
+__device__ unsigned long long g_walk_stats[8];   // diagnostic build only
+#endif
+
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int q, int stack_levels) {
+__global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int q, int stack_levels, int* spill) {
   const uint32_t n = ctl->n_q[q];
   bool more = true;   // wave-uniform: the queue may still have entries
-  const LaneStack st = lane_stack(0, stack_levels);
+  LaneStack st = lane_stack(0, stack_levels);
+  st.spill = spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x; st.spill_stride = (int)(gridDim.x * blockDim.x);
   const bool tree = MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims;
   uint32_t slot = 0;
   Ray<float> ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
@@ -196,13 +237,25 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A
       }
       if (__ballot(state == 1) == 0ull) break;
     }
-    if (state == 1) {
-      bool done = true;
-      if constexpr (MODE != MODE_FLAT) {
-        if (tree) { pair_walk_step<false>(sc, ray, 0.001f, c, w, st); done = w.node == kWalkDone; }
-        else walk_bounded<float, false>(sc, ray, 0.001f, c, st);
+    if constexpr (MODE == MODE_FLAT) {
+      if (state == 1) state = 2;
+    } else if (!tree) {
+      if (state == 1) { walk_bounded<float, false>(sc, ray, 0.001f, c, st); state = 2; }
+    } else {
+      const bool inner = state == 1 && pair_walk_at_inner(w);
+#ifdef RTX_WALK_STATS
+      { const unsigned long long mi = __ballot(inner); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_walk_stats[0], 1ull); if (mi) { atomicAdd(&g_walk_stats[1], 1ull); atomicAdd(&g_walk_stats[2], (unsigned long long)__popcll(mi)); } } }
+#endif
+      if (inner) pair_walk_inner(sc, ray, 0.001f, c, w, st);
+      // leaves wait until a batch of lanes has one, or until no lane has an inner node left
+      const bool leaf = state == 1 && pair_walk_at_leaf(w);
+      if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && pair_walk_at_inner(w)) == 0ull) {
+#ifdef RTX_WALK_STATS
+        { const unsigned long long ml = __ballot(leaf); if ((threadIdx.x & 63) == 0 && ml) { atomicAdd(&g_walk_stats[3], 1ull); atomicAdd(&g_walk_stats[4], (unsigned long long)__popcll(ml)); } }
+#endif
+        if (leaf) pair_walk_leaf<false>(sc, ray, 0.001f, c, w, st);
       }
-      if (done) state = 2;
+      if (state == 1 && w.node == kWalkDone) state = 2;
     }
   }
 }
@@ -228,9 +281,17 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene<float> sc, DRenderPara
   const DMaterial<float>* mats = sc.mats;
   if constexpr (LDS_MATS) mats = stage_materials(sc);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ BlockScratch bs;
   if (i == 0) { ctl->cursor = 0u; ctl->n_q[1 - q] = 0u; }   // wf_extend is done with the cursor; the next wf_generate fills the other queue
-  if (i >= ctl->n_q[q]) return;
-  const uint32_t slot = A.q[q][i];
+  const bool valid = i < ctl->n_q[q];
+  uint32_t did = 0;
+  bool cast = false;           // a light sample needs its visibility ray
+  Ray<float> sh_ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
+  float sh_tmax = 0.f;
+  V3<float> sh_contrib = {0.f, 0.f, 0.f};
+  uint32_t slot = 0;
+  if (valid) {
+  slot = A.q[q][i];
   PathState<float> ps;
   ps.ray.o = {A.ray[0][slot], A.ray[1][slot], A.ray[2][slot]};
   ps.ray.d = {A.ray[3][slot], A.ray[4][slot], A.ray[5][slot]};
@@ -241,12 +302,8 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene<float> sc, DRenderPara
   PathKey key = {A.pixel[slot], P.seed, A.sample[slot] - 1u};
   Hit<float> rec;
   const bool hit = wf_load_hit<MODE>(sc, A, slot, ps.ray, rec);
-  const uint32_t did = path_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<float>& sr, float t_max, V3<float> contrib) {
-    const uint32_t k = wave_append(&ctl->n_shadow);
-    A.sh_slot[k] = slot;
-    A.sh[0][k] = sr.o.x; A.sh[1][k] = sr.o.y; A.sh[2][k] = sr.o.z;
-    A.sh[3][k] = sr.d.x; A.sh[4][k] = sr.d.y; A.sh[5][k] = sr.d.z; A.sh[6][k] = t_max;
-    A.sh_c[0][k] = contrib.x; A.sh_c[1][k] = contrib.y; A.sh_c[2][k] = contrib.z;
+  did = path_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<float>& sr, float t_max, V3<float> contrib) {
+    cast = true; sh_ray = sr; sh_tmax = t_max; sh_contrib = contrib;
   });
   A.ray[0][slot] = ps.ray.o.x; A.ray[1][slot] = ps.ray.o.y; A.ray[2][slot] = ps.ray.o.z;
   A.ray[3][slot] = ps.ray.d.x; A.ray[4][slot] = ps.ray.d.y; A.ray[5][slot] = ps.ray.d.z;
@@ -254,15 +311,23 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene<float> sc, DRenderPara
   A.acc[0][slot] = ps.acc.x; A.acc[1][slot] = ps.acc.y; A.acc[2][slot] = ps.acc.z;
   A.bsdf_pdf[slot] = ps.bsdf_pdf;
   A.bflags[slot] = ps.bounce_flags;
-  wave_count(&counters->segments, (did & STEP_SHADED) != 0);
-  wave_count(&counters->shadow, (did & STEP_SHADOW) != 0);
+  }
+  const uint32_t k = block_append(bs, &ctl->n_shadow, cast);
+  if (cast) {
+    A.sh_slot[k] = slot;
+    A.sh[0][k] = sh_ray.o.x; A.sh[1][k] = sh_ray.o.y; A.sh[2][k] = sh_ray.o.z;
+    A.sh[3][k] = sh_ray.d.x; A.sh[4][k] = sh_ray.d.y; A.sh[5][k] = sh_ray.d.z; A.sh[6][k] = sh_tmax;
+    A.sh_c[0][k] = sh_contrib.x; A.sh_c[1][k] = sh_contrib.y; A.sh_c[2][k] = sh_contrib.z;
+  }
+  block_count2(bs, &counters->segments, (did & STEP_SHADED) != 0, &counters->shadow, (did & STEP_SHADOW) != 0);
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int stack_levels) {
+__global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int stack_levels, int* spill) {
   const uint32_t n = ctl->n_shadow;
   bool more = true;   // wave-uniform: the queue may still have entries
-  const LaneStack st = lane_stack(0, stack_levels);
+  LaneStack st = lane_stack(0, stack_levels);
+  st.spill = spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x; st.spill_stride = (int)(gridDim.x * blockDim.x);
   const bool tree = MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims;
   uint32_t i = 0;
   float t_max = 0.f;
@@ -294,16 +359,18 @@ __global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays 
       }
       if (__ballot(state == 1) == 0ull) break;
     }
-    if (state == 1) {
-      bool done = true, hit;
-      if constexpr (MODE == MODE_FLAT) hit = flat_occluded(sc, sr, 0.001f, t_max);
-      else if (tree) {
-        pair_walk_step<true>(sc, sr, 0.001f, c, w, st);
-        done = w.node == kWalkDone;
-        hit = c.type >= 0;
-        if (done && !hit) hit = occluded_unbounded(sc, sr, 0.001f, t_max);
-      } else hit = occluded(sc, sr, 0.001f, t_max, st);
-      if (done) state = hit ? 2 : 3;
+    if constexpr (MODE == MODE_FLAT) {
+      if (state == 1) state = flat_occluded(sc, sr, 0.001f, t_max) ? 2 : 3;
+    } else if (!tree) {
+      if (state == 1) state = occluded(sc, sr, 0.001f, t_max, st) ? 2 : 3;
+    } else {
+      const bool inner = state == 1 && pair_walk_at_inner(w);
+      if (inner) pair_walk_inner(sc, sr, 0.001f, c, w, st);
+      const bool leaf = state == 1 && pair_walk_at_leaf(w);
+      if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && pair_walk_at_inner(w)) == 0ull) {
+        if (leaf) pair_walk_leaf<true>(sc, sr, 0.001f, c, w, st);
+      }
+      if (state == 1 && w.node == kWalkDone) state = (c.type >= 0 || occluded_unbounded(sc, sr, 0.001f, t_max)) ? 2 : 3;
     }
   }
 }
@@ -311,19 +378,19 @@ __global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays 
 template <int MODE> void launch_iteration_kernels(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, const WfArrays& A, WfControl* ctl,
                                                   float* partial, DCounters* counters, bool lds_mats, size_t mat_lds, int stack_levels, unsigned grid,
                                                   unsigned resident_blocks, int step /*0 first generate, 1 shade, 2 connect, 3 generate*/, int qa, int qb,
-                                                  hipStream_t stream, uint32_t& launches) {
+                                                  hipStream_t stream, uint32_t& launches, int* spill) {
   const dim3 g(grid), b(kBlock);
   const dim3 gw(grid < resident_blocks ? grid : resident_blocks);   // persistent traversal kernels
   const size_t walk_lds = MODE == MODE_FLAT ? 0 : (size_t)stack_levels * kBlock * sizeof(int);
   if (step == 0 || step == 3) {
     hipLaunchKernelGGL(wf_generate, g, b, 0, stream, cam, P, A, ctl, step == 0 ? 1 : 0, qa, qb, partial, counters);
-    hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, qb, stack_levels);
+    hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, qb, stack_levels, spill);
     ++launches;
   } else if (step == 1) {
     if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, b, mat_lds, stream, sc, P, A, ctl, qa, counters);
     else hipLaunchKernelGGL((wf_shade<MODE, false>), g, b, 0, stream, sc, P, A, ctl, qa, counters);
   } else
-    hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, stack_levels);
+    hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, stack_levels, spill);
 }
 
 // Blocks of the traversal kernels one CU keeps resident (the smaller of the two kernels' figures).
@@ -377,11 +444,14 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   const int per_cu = mode == MODE_FLAT ? walk_blocks_per_cu<MODE_FLAT>(stack_levels) : mode == MODE_TREE ? walk_blocks_per_cu<MODE_TREE>(stack_levels)
                                                                                                        : walk_blocks_per_cu<MODE_TREE_UV>(stack_levels);
   const unsigned resident = (unsigned)n_cus * (unsigned)per_cu;
+  // overflow levels of the traversal stacks: the LDS part holds kWalkLdsLevels, the walk can park three children per wide level
+  if (!pool.spill.ensure((size_t)resident * kBlock * (size_t)kStackDepth * sizeof(int))) { err = "pool allocation"; return RTX_ERR_OUT_OF_MEMORY; }
+  int* spill = (int*)pool.spill.ptr;
 
   auto run = [&](int step, int qa, int qb, unsigned grid) {
-    if (mode == MODE_FLAT) launch_iteration_kernels<MODE_FLAT>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches);
-    else if (mode == MODE_TREE) launch_iteration_kernels<MODE_TREE>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches);
-    else launch_iteration_kernels<MODE_TREE_UV>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches);
+    if (mode == MODE_FLAT) launch_iteration_kernels<MODE_FLAT>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill);
+    else if (mode == MODE_TREE) launch_iteration_kernels<MODE_TREE>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill);
+    else launch_iteration_kernels<MODE_TREE_UV>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill);
     ++launches;
   };
   if (hipMemsetAsync(ctl, 0, sizeof(WfControl), stream) != hipSuccess) { err = "memset"; return RTX_ERR_HIP; }
@@ -406,6 +476,15 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   }
   launch_film_reduce(partial, d_film, npix, P.n_chunks, P.spp, stream);
   ++launches;
+#ifdef RTX_WALK_STATS
+  {
+    unsigned long long h[8];
+    hipStreamSynchronize(stream);
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_walk_stats), sizeof h);
+    fprintf(stderr, "walk stats (extend): wave trips %llu, inner phases %llu with %.1f lanes, leaf phases %llu with %.1f lanes\n", h[0], h[1], (double)h[2] / (h[1] ? h[1] : 1),
+            h[3], (double)h[4] / (h[3] ? h[3] : 1));
+  }
+#endif
   return RTX_OK;
 }
 
