@@ -170,6 +170,21 @@ int rtx_render(rtx_ctx* ctx, const rtx_settings* settings, float* out_rgb, rtx_s
  * kernels have finished (stats need the device counters). */
 int rtx_render_device(rtx_ctx* ctx, const rtx_settings* settings, void* d_out_rgb, void* hip_stream, rtx_stats* stats);
 
+/* Replaces Image::apply_tone_mapping followed by the quantisation of Image::write_png / write_ppm
+ * (engine/renderer.cpp:186-198 with the operators of :102-184, then :232-258; called from main.cpp:399-431 on the
+ * GPU branch and renderer.cpp after the CPU render): per channel  c = film * exposure;  tone map;  clamp to [0,1];
+ * sqrt;  (int)(255.999 * v);  rows flipped so that row 0 of `out_rgb8` is the TOP of the image.
+ * tone_mapper follows enum class ToneMapper (engine/renderer.hpp:39-45).  Computed in double precision in the
+ * reference's operation order: the bytes equal the reference's for the same float film.  A NaN channel gives 0.
+ * `film_rgb`: width*height*3 floats, row 0 = bottom (what rtx_render returns); both buffers are host memory. */
+enum { RTX_TONE_NONE = 0, RTX_TONE_REINHARD = 1, RTX_TONE_REINHARD_EXTENDED = 2, RTX_TONE_ACES = 3, RTX_TONE_UNCHARTED2 = 4 };
+int rtx_postprocess(rtx_ctx* ctx, const float* film_rgb, int width, int height, int tone_mapper, double exposure, uint8_t* out_rgb8);
+
+/* Same on DEVICE buffers of the context's device, enqueued on `hip_stream` (NULL = the context's stream); returns
+ * after the kernel has finished. */
+int rtx_postprocess_device(rtx_ctx* ctx, const void* d_film_rgb, int width, int height, int tone_mapper, double exposure, void* d_out_rgb8,
+                           void* hip_stream);
+
 /* Closest-hit validation entry point: the GPU counterpart of Scene::hit
  * (engine/scene.hpp:574-674) in double precision on the reference-order BVH.
  * rays8: n records of 8 doubles (origin xyz, direction xyz, t_min, t_max), host memory. */

@@ -104,6 +104,19 @@ class OracleScene:
         return out[: w.value].copy()
 
 
+def postprocess(film, tone_mapper, exposure):
+    """uint8 [H, W, 3], row 0 = top (orc_postprocess)."""
+    f = np.ascontiguousarray(film, dtype=np.float32)
+    H, W, _ = f.shape
+    out = np.zeros((H, W, 3), dtype=np.uint8)
+    L = lib()
+    L.orc_postprocess.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    L.orc_postprocess.restype = C.c_int
+    rc = L.orc_postprocess(f.ctypes.data, W, H, int(tone_mapper), float(exposure), out.ctypes.data)
+    assert rc == 0
+    return out
+
+
 def philox(ctr, key):
     c = np.asarray(ctr, dtype=np.uint32)
     k = np.asarray(key, dtype=np.uint32)

@@ -1076,3 +1076,40 @@ int orc_kat(const orc_scene* s, unsigned seed, int n, double* out, size_t cap, s
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// post-process (engine/renderer.cpp:102-198 tone mapping operators, :232-258 quantisation)
+// ------------------------------------------------------------------------------------------
+namespace {
+double pp_clamp01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }            // std::clamp(v, 0.0, 1.0)
+double pp_u2_partial(double x) {                                                          // renderer.cpp:131-139
+  const double A = 0.15, B = 0.50, C = 0.10, D = 0.20, E = 0.02, F = 0.30;
+  return ((x * (A * x + C * B) + D * E) / (x * (A * x + B) + D * F)) - E / F;
+}
+double pp_tone(double x, int mapper) {                                                    // renderer.cpp:155-184
+  switch (mapper) {
+    case 1: return x / (1.0 + x);                                                         // :106-108
+    case 2: { const double wp2 = 4.0 * 4.0; return x * (1.0 + x / wp2) / (1.0 + x); }      // :114-117
+    case 3: { const double a = 2.51, b = 0.03, c = 2.43, d = 0.59, e = 0.14;             // :123-130
+              return pp_clamp01((x * (a * x + b)) / (x * (c * x + d) + e)); }
+    case 4: { const double curr = pp_u2_partial(x * 2.0);                                  // :144-150
+              const double white_scale = 1.0 / pp_u2_partial(11.2);
+              return curr * white_scale; }
+    default: return pp_clamp01(x);
+  }
+}
+}  // namespace
+
+extern "C" int orc_postprocess(const float* film, int width, int height, int tone_mapper, double exposure, uint8_t* rgb8) {
+  if (!film || !rgb8 || width <= 0 || height <= 0) return RTX_ERR_INVALID_ARGUMENT;
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x)
+      for (int ch = 0; ch < 3; ++ch) {
+        const double c = (double)film[((size_t)y * width + x) * 3 + ch] * exposure;   // :189-193
+        const double m = pp_tone(c, tone_mapper);
+        const double g = std::sqrt(pp_clamp01(m));                                      // :241-243
+        const int iv = (int)(255.999 * g);                                              // :246-248
+        rgb8[((size_t)(height - 1 - y) * width + x) * 3 + ch] = (uint8_t)iv;            // :251-255
+      }
+  return RTX_OK;
+}

@@ -41,6 +41,12 @@ int orc_render(const orc_scene* s, const rtx_camera* cam, const rtx_settings* st
 /* Scalar known-answer stream; mirrors `ref_harness kat` draw for draw. */
 int orc_kat(const orc_scene* s, unsigned seed, int n, double* out, size_t cap, size_t* written);
 
+/* Image::apply_tone_mapping + the quantisation of Image::write_png (engine/renderer.cpp:102-198, :232-258):
+ * exposure, tone map (ToneMapper enum order: 0 None, 1 Reinhard, 2 ReinhardExtended, 3 ACES, 4 Uncharted2), clamp,
+ * sqrt gamma, int(255.999 * v), vertical flip.  `film`: width*height*3 floats, row 0 = bottom;
+ * `rgb8`: width*height*3 bytes, row 0 = TOP. */
+int orc_postprocess(const float* film, int width, int height, int tone_mapper, double exposure, uint8_t* rgb8);
+
 /* The counter-based generator, exposed so tests can pin it (Random123 known answers). */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -357,10 +357,27 @@ int cmd_texels(const char* scene_path, const char* prefix) {
   return 0;
 }
 
+// Post-process of a film through the reference's own code: Image::apply_tone_mapping followed by
+// Image::write_ppm (engine/renderer.cpp:186-230).  <film.f32> holds width*height*3 floats, row 0 = bottom.
+int cmd_post(const char* film_path, int w, int h, int mapper, double exposure, const char* ppm_path) {
+  std::vector<float> film((size_t)w * h * 3);
+  FILE* f = fopen(film_path, "rb");
+  if (!f || fread(film.data(), 4, film.size(), f) != film.size()) { fprintf(stderr, "cannot read %s\n", film_path); return 1; }
+  fclose(f);
+  Image img(w, h);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const float* p = &film[((size_t)y * w + x) * 3];
+      img.set_pixel(x, y, color{(double)p[0], (double)p[1], (double)p[2]});
+    }
+  img.apply_tone_mapping((ToneMapper)mapper, exposure);
+  return img.write_ppm(ppm_path) ? 0 : 1;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc < 3) { fprintf(stderr, "usage: ref_harness dump|bvh|hits|render|kat ...\n"); return 2; }
+  if (argc < 3) { fprintf(stderr, "usage: ref_harness dump|bvh|hits|render|kat|texels|post ...\n"); return 2; }
   std::string cmd = argv[1];
   if (cmd == "dump") return cmd_dump(argv[2]);
   if (cmd == "bvh" && argc >= 4) return cmd_bvh(argv[2], argv[3], argc > 4 ? argv[4] : nullptr);
@@ -368,6 +385,7 @@ int main(int argc, char** argv) {
   if (cmd == "render") return cmd_render(argc, argv);
   if (cmd == "kat" && argc >= 6) return cmd_kat(argv[2], (unsigned)strtoul(argv[3], nullptr, 10), atoi(argv[4]), argv[5]);
   if (cmd == "texels" && argc >= 4) return cmd_texels(argv[2], argv[3]);
+  if (cmd == "post" && argc >= 8) return cmd_post(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atof(argv[6]), argv[7]);
   fprintf(stderr, "bad command\n");
   return 2;
 }

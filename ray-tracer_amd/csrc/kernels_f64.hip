@@ -87,4 +87,42 @@ int launch_trace_fast(const DScene<double>& sc, const double* rays8, unsigned lo
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Post-process: exposure, tone map, clamp, sqrt gamma, 255.999 quantisation, vertical flip
+// (ref: engine/renderer.cpp:102-198, :232-258).  One thread per channel value; double precision,
+// no contraction (this file is built with -ffp-contract=off), so the bytes equal the reference's.
+// ------------------------------------------------------------------------------------------
+namespace {
+RTX_DEV double pp_clamp01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
+RTX_DEV double pp_u2_partial(double x) {   // ref: renderer.cpp:131-139
+  const double A = 0.15, B = 0.50, C = 0.10, D = 0.20, E = 0.02, F = 0.30;
+  return ((x * (A * x + C * B) + D * E) / (x * (A * x + B) + D * F)) - E / F;
+}
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ film, unsigned char* __restrict__ out, int width, int height, int mapper,
+                                                         double exposure) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long row = (unsigned long long)width * 3ull;
+  if (i >= row * (unsigned long long)height) return;
+  const unsigned long long y = i / row, within = i - y * row;
+  const double x = (double)film[i] * exposure;   // ref: renderer.cpp:189-193
+  double m;
+  switch (mapper) {                              // ref: renderer.cpp:155-184
+    case RTX_TONE_REINHARD: m = x / (1.0 + x); break;
+    case RTX_TONE_REINHARD_EXTENDED: { const double wp2 = 4.0 * 4.0; m = x * (1.0 + x / wp2) / (1.0 + x); break; }
+    case RTX_TONE_ACES: { const double a = 2.51, b = 0.03, c = 2.43, d = 0.59, e = 0.14; m = pp_clamp01((x * (a * x + b)) / (x * (c * x + d) + e)); break; }
+    case RTX_TONE_UNCHARTED2: { const double curr = pp_u2_partial(x * 2.0); const double white_scale = 1.0 / pp_u2_partial(11.2); m = curr * white_scale; break; }
+    default: m = pp_clamp01(x); break;
+  }
+  const double g = sqrt(pp_clamp01(m));          // ref: renderer.cpp:241-243
+  const double q = 255.999 * g;                  // ref: renderer.cpp:246-248
+  const int iv = q == q ? (int)q : 0;
+  out[((unsigned long long)height - 1ull - y) * row + within] = (unsigned char)iv;   // ref: renderer.cpp:251-255
+}
+}  // namespace
+
+void launch_postprocess(const float* film, unsigned char* out, int width, int height, int mapper, double exposure, hipStream_t stream) {
+  const unsigned long long n = (unsigned long long)width * height * 3ull;
+  hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, film, out, width, height, mapper, exposure);
+}
+
 }  // namespace rtx

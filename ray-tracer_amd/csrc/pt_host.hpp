@@ -61,6 +61,7 @@ int launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, co
                         const FusedLaunch& L, hipStream_t stream);
 void launch_film_reduce(const float* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream);
 void launch_film_reduce(const double* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream);
+void launch_postprocess(const float* film, unsigned char* out, int width, int height, int mapper, double exposure, hipStream_t stream);
 int launch_trace_fast(const DScene<float>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream);
 int launch_trace_fast(const DScene<double>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream);
 void launch_trace_ref(const DScene<double>& sc, const DSceneRef& ref, const double* rays8, unsigned long long n, DHitOut* out, hipStream_t stream);

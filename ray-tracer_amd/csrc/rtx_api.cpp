@@ -49,7 +49,7 @@ struct rtx_ctx {
   HostScene scene;          // device-resident copies + BVHs
   DCamera<float> cam_f;
   DCamera<double> cam_d;
-  DeviceBuffer partial, film, counters, rays, hits;
+  DeviceBuffer partial, film, counters, rays, hits, post_in, post_out;
   WavefrontPool wf;         // wavefront-pipeline queues, allocated on first use
 };
 
@@ -104,7 +104,7 @@ int rtx_destroy(rtx_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   c->scene.release();
-  c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release();
+  c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release(); c->post_in.release(); c->post_out.release();
   c->wf.release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -259,6 +259,41 @@ int rtx_render(rtx_ctx* c, const rtx_settings* s, float* out_rgb, rtx_stats* sta
 int rtx_render_device(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* hip_stream, rtx_stats* stats) {
   if (!d_out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "d_out_rgb is NULL");
   return render_impl(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, stats);
+}
+
+static int postprocess_impl(rtx_ctx* c, const float* h_film, const void* d_film, int width, int height, int mapper, double exposure, uint8_t* h_out,
+                            void* d_out, hipStream_t user_stream) {
+  if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL context");
+  if (width <= 0 || height <= 0 || (unsigned long long)width * height > 0x7fffffffull / 3ull)
+    return fail(RTX_ERR_INVALID_ARGUMENT, "bad image size %dx%d", width, height);
+  if (mapper < RTX_TONE_NONE || mapper > RTX_TONE_UNCHARTED2) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown tone mapper %d", mapper);
+  if (!(exposure == exposure)) return fail(RTX_ERR_INVALID_ARGUMENT, "exposure is NaN");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t stream = user_stream ? user_stream : c->stream;
+  const size_t n = (size_t)width * height * 3;
+  const float* in = (const float*)d_film;
+  unsigned char* out = (unsigned char*)d_out;
+  if (h_film) {
+    if (!c->post_in.ensure(n * sizeof(float)) || !c->post_out.ensure(n)) return fail(RTX_ERR_OUT_OF_MEMORY, "post-process buffers (%zu values)", n);
+    HIP_TRY(hipMemcpyAsync(c->post_in.ptr, h_film, n * sizeof(float), hipMemcpyHostToDevice, stream));
+    in = (const float*)c->post_in.ptr;
+    out = (unsigned char*)c->post_out.ptr;
+  }
+  launch_postprocess(in, out, width, height, mapper, exposure, stream);
+  HIP_TRY(hipGetLastError());
+  if (h_out) HIP_TRY(hipMemcpyAsync(h_out, out, n, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  return RTX_OK;
+}
+
+int rtx_postprocess(rtx_ctx* c, const float* film_rgb, int width, int height, int tone_mapper, double exposure, uint8_t* out_rgb8) {
+  if (!film_rgb || !out_rgb8) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL buffer");
+  return postprocess_impl(c, film_rgb, nullptr, width, height, tone_mapper, exposure, out_rgb8, nullptr, nullptr);
+}
+
+int rtx_postprocess_device(rtx_ctx* c, const void* d_film_rgb, int width, int height, int tone_mapper, double exposure, void* d_out_rgb8, void* hip_stream) {
+  if (!d_film_rgb || !d_out_rgb8) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL buffer");
+  return postprocess_impl(c, nullptr, d_film_rgb, width, height, tone_mapper, exposure, nullptr, d_out_rgb8, (hipStream_t)hip_stream);
 }
 
 static int trace_impl(rtx_ctx* c, const double* rays8, size_t n, rtx_hit* out, int mode /*0 ref, 1 fast f32, 2 fast f64*/) {

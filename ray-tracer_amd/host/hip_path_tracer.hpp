@@ -38,6 +38,11 @@ class HipPathTracer {
     if (!have_settings_) { status_ = RTX_ERR_NOT_READY; std::fprintf(stderr, "HIP render: set_settings was not called\n"); return; }
     note(rtx_render(ctx_, &settings_, output, &stats_), "render");
   }
+  // exposure -> tone map -> sqrt gamma -> 8-bit, rows flipped to top-first
+  // (ref: Image::apply_tone_mapping + Image::write_png, engine/renderer.cpp:186-198, :232-258)
+  void postprocess(const float* film, int width, int height, int tone_mapper, double exposure, unsigned char* out_rgb8) {
+    if (ctx_) note(rtx_postprocess(ctx_, film, width, height, tone_mapper, exposure, out_rgb8), "postprocess");
+  }
   void trace_closest(const double* rays8, size_t n, rtx_hit* out) { if (ctx_) note(rtx_trace_closest(ctx_, rays8, n, out), "trace_closest"); }
 
   bool ok() const { return status_ == RTX_OK; }

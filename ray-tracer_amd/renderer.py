@@ -86,6 +86,22 @@ class HipPathTracer:
         self.last_stats = stats
         return stats
 
+    def postprocess(self, film: np.ndarray, tone_mapper: int = TM_ACES, exposure: float = 1.0) -> np.ndarray:
+        """Image::apply_tone_mapping + the quantisation of Image::write_png (engine/renderer.cpp:186-198,
+        :232-258) on the GPU: uint8 [H, W, 3], row 0 = TOP, from a float film with row 0 = bottom."""
+        film = np.ascontiguousarray(film, dtype=np.float32)
+        h, w, ch = film.shape
+        assert ch == 3
+        out = np.empty((h, w, 3), dtype=np.uint8)
+        abi.check(self._lib, self._lib.rtx_postprocess(self._ctx, film.ctypes.data_as(C.POINTER(C.c_float)), w, h, int(tone_mapper), float(exposure),
+                                                       out.ctypes.data_as(C.POINTER(C.c_uint8))), "rtx_postprocess")
+        return out
+
+    def postprocess_device(self, film_ptr: int, width: int, height: int, out_ptr: int, tone_mapper: int = TM_ACES, exposure: float = 1.0, stream: int = 0):
+        """Same on device buffers (e.g. torch tensors' data_ptr on this device)."""
+        abi.check(self._lib, self._lib.rtx_postprocess_device(self._ctx, C.c_void_p(film_ptr), width, height, int(tone_mapper), float(exposure),
+                                                              C.c_void_p(out_ptr), C.c_void_p(stream)), "rtx_postprocess_device")
+
     def trace_closest(self, rays8: np.ndarray, fast_precision: int | None = None) -> np.ndarray:
         """Closest hits for rays [n, 8] = (origin, direction, t_min, t_max).  Default: the
         double-precision reference-order kernel; fast_precision selects the production BVH."""
@@ -141,6 +157,15 @@ def tone_map(film: np.ndarray, mapper: int = TM_ACES, exposure: float = 1.0) -> 
             return ((x * (A * x + Cc * B) + D * E) / (x * (A * x + B) + D * F)) - E / F
         return part(c * 2.0) * (1.0 / part(11.2))
     return np.clip(c, 0.0, 1.0)  # ToneMapper::None still clamps (renderer.cpp:175-182)
+
+
+def write_ppm(path: str, rgb8: np.ndarray) -> None:
+    """Image::write_ppm's file format (engine/renderer.cpp:202-230): plain-text P3, one pixel per line,
+    top row first.  `rgb8` is uint8 [H, W, 3] with row 0 = top (what `HipPathTracer.postprocess` returns)."""
+    h, w, _ = rgb8.shape
+    with open(path, "w") as f:
+        f.write(f"P3\n{w} {h}\n255\n")
+        f.write("".join(f"{r} {g} {b}\n" for r, g, b in rgb8.reshape(-1, 3).tolist()))
 
 
 def quantize(mapped: np.ndarray) -> np.ndarray:

@@ -129,6 +129,40 @@ def ref_film(name, W, H, spp, depth, seed, nee=1, mis=1, mnee=0, threads=1):
     return np.frombuffer(raw[8:].tobytes(), dtype=np.float64).reshape(H, W, 3).copy(), secs
 
 
+def post_test_film(W=48, H=20, seed=5):
+    """A float film that exercises every branch of the post-process: zeros, tiny, mid, > 1, huge, negative."""
+    rng = np.random.default_rng(seed)
+    film = np.exp(rng.uniform(-12.0, 4.0, size=(H, W, 3))).astype(np.float32)
+    film[0, :8] = [0.0, 1.0, 0.5]
+    film[1, :8] = [-0.25, 1e-8, 1e6]
+    film[2, :8] = np.linspace(0.0, 2.0, 24, dtype=np.float32).reshape(8, 3)
+    return film
+
+
+def ref_post(film, mapper, exposure):
+    """uint8 [H, W, 3], row 0 = top, through Image::apply_tone_mapping + Image::write_ppm of the reference."""
+    H, W, _ = film.shape
+    with tempfile.TemporaryDirectory() as td:
+        fp, op = os.path.join(td, "film.f32"), os.path.join(td, "out.ppm")
+        film.astype(np.float32).tofile(fp)
+        run(["post", fp, W, H, mapper, repr(float(exposure)), op])
+        tok = open(op).read().split()
+    assert tok[0] == "P3" and int(tok[1]) == W and int(tok[2]) == H and tok[3] == "255"
+    return np.array(tok[4:], dtype=np.int64).reshape(H, W, 3).astype(np.uint8)
+
+
+def make_post_fixtures():
+    os.makedirs(os.path.join(HERE, "post"), exist_ok=True)
+    film = post_test_film()
+    out = {"film": film}
+    for mapper in range(5):
+        for k, exposure in enumerate((1.0, 0.35, 2.5)):
+            out[f"m{mapper}_e{k}"] = ref_post(film, mapper, exposure)
+    out["exposures"] = np.array([1.0, 0.35, 2.5])
+    np.savez_compressed(os.path.join(HERE, "post", "post.npz"), **out)
+    print("post fixtures", len(out) - 2)
+
+
 def rel_mse(x, r):
     x = np.clip(x, 0.0, 1.0); r = np.clip(r, 0.0, 1.0)   # the film Renderer::render returns is clamped
     return float(np.mean((x - r) ** 2 / (r ** 2 + 1e-2)))
@@ -139,6 +173,9 @@ def main():
         subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "ref"])
     for sub in ("loader", "hits", "bvh", "films", "converged", "kat"):
         os.makedirs(os.path.join(HERE, sub), exist_ok=True)
+    make_post_fixtures()
+    if "--post-only" in sys.argv:
+        return
 
     names = ["cornell_box", "cornell_box_quad", "caustics_test", "environment_demo", "earth_demo", "demo", "kitchen_sink", "textured", "disk_room"]
     docs = {n: dump_loader(n) for n in names}

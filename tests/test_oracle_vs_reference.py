@@ -188,3 +188,37 @@ def test_counter_mode_estimator_matches_reference_statistically(name, oracle, lo
     assert rel_mse(film, ref) <= 1.25 * float(fx["noise_floor_relmse"])
     mg, mr = np.clip(film, 0, 1).mean(axis=(0, 1)), np.clip(ref, 0, 1).mean(axis=(0, 1))
     assert np.all(np.abs(mg - mr) / mr < 0.015), (mg, mr)
+
+
+# ---- post-process (engine/renderer.cpp:102-261) ---------------------------------------------------
+def _post_fixture():
+    return np.load(os.path.join(GOLDEN, "post", "post.npz"))
+
+
+@pytest.mark.parametrize("mapper", [0, 1, 2, 3, 4])
+def test_postprocess_oracle_equals_reference_bytes(mapper, oracle):
+    """orc_postprocess against Image::apply_tone_mapping + Image::write_ppm of the real reference, byte for byte,
+    on a film with zeros, negatives, values above one and 1e6 (tests/golden/make_fixtures.py: make_post_fixtures)."""
+    fx = _post_fixture()
+    for k, exposure in enumerate(fx["exposures"]):
+        got = oracle.postprocess(fx["film"], mapper, float(exposure))
+        assert np.array_equal(got, fx[f"m{mapper}_e{k}"]), (mapper, exposure)
+
+
+def test_postprocess_numpy_mirror_and_ppm_writer(pkg, tmp_path):
+    """The host-side numpy mirrors (renderer.tone_map / quantize) give the same bytes, and write_ppm produces the
+    reference's file format (P3, one pixel per line, top row first)."""
+    fx = _post_fixture()
+    r = pkg.renderer
+    for mapper in range(5):
+        for k, exposure in enumerate(fx["exposures"]):
+            got = r.quantize(r.tone_map(fx["film"], mapper, float(exposure)))
+            want = fx[f"m{mapper}_e{k}"]
+            assert (got != want).mean() < 2e-4 and np.abs(got.astype(int) - want.astype(int)).max() <= 1   # numpy may fuse nothing but orders sums differently
+    path = tmp_path / "x.ppm"
+    r.write_ppm(str(path), fx["m3_e0"])
+    tok = path.read_text().split()
+    H, W, _ = fx["film"].shape
+    assert tok[:4] == ["P3", str(W), str(H), "255"]
+    assert np.array_equal(np.array(tok[4:], dtype=np.int64).reshape(H, W, 3), fx["m3_e0"])
+    assert path.read_text().count("\n") == 3 + W * H
