@@ -555,6 +555,8 @@ struct MtSampler {
   double light_v() { return next(); }
   double fresnel() { return next(); }
   double roulette() { return next(); }
+  // the two uniforms MNEE::evaluate draws for its j-th light, in order (mnee.hpp:645, :678, :718-720)
+  void mnee_pair(int, double& a, double& b) { a = next(); b = next(); }
   V3 unit_vector() {  // random_in_unit_sphere + normalize, renderer.cpp:45-56
     for (;;) {
       double a = range(-1, 1), b = range(-1, 1), c = range(-1, 1);
@@ -589,6 +591,12 @@ struct CounterSampler {
   double light_select() { return hi(W()[2]); }
   double roulette() { return lo(W()[2]); }
   double fresnel() { return hi(W()[3]); }
+  // MNEE light j of this vertex: extra block (1 + bounce) | ((1 + j / 4) << 16), word j % 4, high | low field
+  void mnee_pair(int j, double& a, double& b) {
+    uint32_t c[4] = {sample, (1u + (uint32_t)bounce) | ((1u + (uint32_t)j / 4u) << 16), 0, 0}, o[4];
+    philox4x32_10(c, key, o);
+    a = hi(o[j & 3]); b = lo(o[j & 3]);
+  }
   V3 unit_vector() {  // uniform on the sphere: same law as the normalised rejection sample
     double z = 1.0 - 2.0 * hi(W()[1]);
     double r = std::sqrt(std::fmax(0.0, 1.0 - z * z));
@@ -601,6 +609,19 @@ struct CounterSampler {
 // light sampling — engine/scene.hpp:238-388 (sample), :407-463 (pdf), :470-488 (env pdf)
 // ----------------------------------------------------------------------------------------
 struct LightPick { V3 pos, n, Le; double pdf = 0, dist = 0; bool valid = false; };
+
+inline V3 disk_sample_point(const rtx_disk_light& dl, double u, double v) {  // DiskLight::sample_point, primitives.hpp:350-384
+  double sx = 2.0 * u - 1.0, sy = 2.0 * v - 1.0;
+  V3 c = mk(dl.center);
+  if (sx == 0 && sy == 0) return c;
+  double rs, theta;
+  if (std::fabs(sx) > std::fabs(sy)) { rs = sx; theta = (kPi / 4.0) * (sy / sx); }
+  else { rs = sy; theta = (kPi / 2.0) - (kPi / 4.0) * (sx / sy); }
+  double ct = std::cos(theta), st = std::sin(theta);
+  double ar = dl.radius * rs;
+  V3 offv = add(scale(mk(dl.tangent), ar * ct), scale(mk(dl.bitangent), ar * st));
+  return add(c, offv);
+}
 
 template <class S>
 LightPick sample_light(const orc_scene& s, V3 from, S& rng) {
@@ -668,19 +689,7 @@ LightPick sample_light(const orc_scene& s, V3 from, S& rng) {
   if (!out.valid && idx < off + nd) {  // DiskLight::sample_point, primitives.hpp:350-384
     const rtx_disk_light& dl = s.disks[idx - off];
     double u = rng.light_u(), v = rng.light_v();
-    double sx = 2.0 * u - 1.0, sy = 2.0 * v - 1.0;
-    V3 c = mk(dl.center);
-    if (sx == 0 && sy == 0) {
-      out.pos = c;
-    } else {
-      double rs, theta;
-      if (std::fabs(sx) > std::fabs(sy)) { rs = sx; theta = (kPi / 4.0) * (sy / sx); }
-      else { rs = sy; theta = (kPi / 2.0) - (kPi / 4.0) * (sx / sy); }
-      double ct = std::cos(theta), st = std::sin(theta);
-      double ar = dl.radius * rs;
-      V3 offv = add(scale(mk(dl.tangent), ar * ct), scale(mk(dl.bitangent), ar * st));
-      out.pos = add(c, offv);
-    }
+    out.pos = disk_sample_point(dl, u, v);
     out.n = mk(dl.normal); out.Le = mk(dl.emission);
     out.pdf = 1.0 / dl.area;
     out.dist = len(sub(out.pos, from));
@@ -751,7 +760,247 @@ V3 background(const orc_scene& s, const rtx_settings& st, const Ray& r) {  // re
   return mk(st.background_color);
 }
 
-// Renderer::ray_color_path — engine/renderer.cpp:580-841, use_mnee = false.
+// Renderer::ray_color_path — engine/renderer.cpp:580-841.
+// ----------------------------------------------------------------------------------------
+// Manifold next event estimation — engine/spectral/mnee.hpp (called at engine/renderer.cpp:716-732)
+// ----------------------------------------------------------------------------------------
+struct MVertex { V3 p, n; double eta; int mat; };   // ManifoldVertex, mnee.hpp:32-39 (members the solver reads)
+constexpr int kMneeMaxIter = 20, kMneeMaxDepth = 4;  // mnee.hpp:59-60
+constexpr double kMneeEps = 1e-6, kMneeStepEps = 1e-10;
+
+inline void mnee_frame(V3 n, V3& t, V3& b) {  // mnee.hpp:299-304
+  V3 up = (std::fabs(n.y) < 0.9) ? V3{0, 1, 0} : V3{1, 0, 0};
+  t = normalize(cross(up, n));
+  b = cross(n, t);
+}
+inline void mnee_constraint(V3 prev, V3 cur, V3 next, double eta, V3 t, V3 b, double& cu, double& cv) {  // mnee.hpp:328-347
+  V3 wi = normalize(sub(prev, cur)), wo = normalize(sub(next, cur));
+  double wi_u = dot(wi, t), wi_v = dot(wi, b), wo_u = dot(wo, t), wo_v = dot(wo, b);
+  cu = eta * wi_u + wo_u; cv = eta * wi_v + wo_v;
+}
+inline bool mnee_reproject(const orc_scene& s, V3& pos, V3& n, int expected, Tally& tl) {  // mnee.hpp:401-437
+  V3 dirs[2] = {n, neg(n)};
+  for (int d = 0; d < 2; ++d) {
+    Hit rec; tl.closest++;
+    if (scene_hit(s, Ray{pos, dirs[d]}, 0.0, 0.1, rec)) {
+      if (rec.mat == expected) { pos = rec.p; n = rec.n; return true; }
+    }
+  }
+  V3 off = add(pos, scale(n, 0.05));
+  Hit rec; tl.closest++;
+  if (scene_hit(s, Ray{off, neg(n)}, 0.0, 0.2, rec)) {
+    if (rec.mat == expected) { pos = rec.p; n = rec.n; return true; }
+  }
+  return false;
+}
+// build_path, mnee.hpp:538-617: throughput of the chain, then a visibility walk along it
+inline bool mnee_build_path(const orc_scene& s, V3 sp, V3 lp, const MVertex* ch, int n, double& throughput, Tally& tl) {
+  throughput = 1.0;
+  for (int i = 0; i < n; ++i) {
+    V3 prev = (i == 0) ? sp : ch[i - 1].p, next = (i == n - 1) ? lp : ch[i + 1].p, cur = ch[i].p;
+    V3 wi = normalize(sub(prev, cur)), wo = normalize(sub(next, cur));
+    double eta = ch[i].eta;
+    double cos_i = std::fabs(dot(wi, ch[i].n)), cos_t = std::fabs(dot(wo, ch[i].n));
+    double r0 = (1.0 - eta) / (1.0 + eta);
+    r0 = r0 * r0;
+    double fr = r0 + (1.0 - r0) * std::pow(1.0 - cos_i, 5.0);
+    double ft = 1.0 - fr;
+    double geometry = (eta * eta * cos_t) / cos_i;
+    throughput *= ft * geometry;
+    if (throughput < 1e-10) return false;
+  }
+  V3 current = sp;
+  for (int i = 0; i <= n; ++i) {
+    V3 target = (i == n) ? lp : ch[i].p;
+    V3 dir = normalize(sub(target, current));
+    double dist = len(sub(target, current));
+    Hit rec; tl.closest++;
+    if (scene_hit(s, Ray{current, dir}, 0.001, dist - 0.001, rec)) {
+      if (i < n) {
+        double hd = len(sub(rec.p, ch[i].p));
+        if (hd > 0.01) return false;
+      } else return false;
+    }
+    if (i < n) current = ch[i].p;
+  }
+  return true;
+}
+// solve_manifold, mnee.hpp:442-533: Gauss-Seidel Newton on the per-vertex refraction constraints
+inline bool mnee_solve(const orc_scene& s, V3 sp, V3 lp, MVertex* ch, int n, double& throughput, Tally& tl) {
+  V3 tg[kMneeMaxDepth], bt[kMneeMaxDepth];
+  for (int i = 0; i < n; ++i) mnee_frame(ch[i].n, tg[i], bt[i]);
+  for (int iter = 0; iter < kMneeMaxIter; ++iter) {
+    double max_c = 0.0, cu[kMneeMaxDepth], cv[kMneeMaxDepth];
+    for (int i = 0; i < n; ++i) {
+      V3 prev = (i == 0) ? sp : ch[i - 1].p, next = (i == n - 1) ? lp : ch[i + 1].p;
+      mnee_constraint(prev, ch[i].p, next, ch[i].eta, tg[i], bt[i], cu[i], cv[i]);
+      double mag = std::sqrt(cu[i] * cu[i] + cv[i] * cv[i]);
+      max_c = std::fmax(max_c, mag);
+    }
+    if (max_c < kMneeEps) return mnee_build_path(s, sp, lp, ch, n, throughput, tl);
+    for (int i = 0; i < n; ++i) {
+      V3 prev = (i == 0) ? sp : ch[i - 1].p, next = (i == n - 1) ? lp : ch[i + 1].p;
+      const double h = 1e-5;   // compute_jacobian_block, mnee.hpp:354-382
+      double c0u, c0v, cuu, cuv, cvu, cvv;
+      mnee_constraint(prev, ch[i].p, next, ch[i].eta, tg[i], bt[i], c0u, c0v);
+      mnee_constraint(prev, add(ch[i].p, scale(tg[i], h)), next, ch[i].eta, tg[i], bt[i], cuu, cuv);
+      mnee_constraint(prev, add(ch[i].p, scale(bt[i], h)), next, ch[i].eta, tg[i], bt[i], cvu, cvv);
+      double J00 = (cuu - c0u) / h, J01 = (cvu - c0u) / h, J10 = (cuv - c0v) / h, J11 = (cvv - c0v) / h;
+      double b0 = -cu[i], b1 = -cv[i], st0, st1;
+      double det = J00 * J11 - J01 * J10;   // solve_2x2, mnee.hpp:387-396
+      if (std::fabs(det) < kMneeStepEps) { st0 = -0.5 * cu[i]; st1 = -0.5 * cv[i]; }
+      else { double inv = 1.0 / det; st0 = inv * (J11 * b0 - J01 * b1); st1 = inv * (-J10 * b0 + J00 * b1); }
+      double mag = std::sqrt(st0 * st0 + st1 * st1);
+      if (mag > 0.1) { double sc = 0.1 / mag; st0 *= sc; st1 *= sc; }
+      V3 delta = add(scale(tg[i], st0), scale(bt[i], st1));
+      ch[i].p = add(ch[i].p, delta);
+      mnee_reproject(s, ch[i].p, ch[i].n, ch[i].mat, tl);
+      mnee_frame(ch[i].n, tg[i], bt[i]);
+    }
+  }
+  return false;
+}
+// connect_to_light_straight, mnee.hpp:94-143
+inline bool mnee_straight(const orc_scene& s, V3 sp, V3 lp, double& throughput, Tally& tl) {
+  V3 to_light = sub(lp, sp);
+  double dist = len(to_light);
+  V3 dir = scale(to_light, 1.0 / dist);
+  MVertex ch[kMneeMaxDepth];
+  int n = 0;
+  Ray probe{sp, dir};
+  V3 cur = sp;
+  for (int i = 0; i < kMneeMaxDepth; ++i) {
+    Hit rec;
+    double max_t = len(sub(lp, cur)) - kMneeEps;
+    tl.closest++;
+    if (!scene_hit(s, probe, 0.001, max_t, rec)) break;
+    // a quad / disk light in the way has a negative id (the reference indexes its material array with it:
+    // undefined behaviour); defined here as "not a dielectric"
+    if (rec.mat < 0 || s.mats[rec.mat].type != RTX_MAT_DIELECTRIC) return false;
+    const rtx_material& m = s.mats[rec.mat];
+    ch[n].p = rec.p; ch[n].n = rec.n;
+    ch[n].eta = rec.front ? (1.0 / m.refraction_index) : m.refraction_index;
+    ch[n].mat = rec.mat;
+    ++n;
+    cur = rec.p;
+    probe = Ray{add(cur, scale(dir, 0.001)), dir};
+  }
+  if (n == 0) return false;
+  return mnee_solve(s, sp, lp, ch, n, throughput, tl);
+}
+// try_sphere_seed_path, mnee.hpp:194-295
+inline bool mnee_sphere_seed(const orc_scene& s, const rtx_sphere& sph, const rtx_material& m, V3 sp, V3 lp, double& throughput, Tally& tl) {
+  V3 to_light = normalize(sub(lp, sp)), to_shade = normalize(sub(sp, lp));
+  V3 c = mk(sph.center);
+  V3 pts[2], nrm[2];
+  const V3 origins[2] = {sp, lp}, dirs[2] = {to_light, to_shade};
+  for (int k = 0; k < 2; ++k) {
+    Hit rec;
+    if (!hit_sphere(sph, Ray{origins[k], dirs[k]}, 0.001, 1e9, rec)) {
+      V3 to_center = sub(c, origins[k]);
+      double proj = dot(to_center, dirs[k]);
+      if (proj < 0) return false;
+      V3 closest = add(origins[k], scale(dirs[k], proj));
+      V3 to_closest = sub(c, closest);
+      double da = len(to_closest);
+      if (da >= sph.radius) {
+        V3 d2 = normalize(sub(closest, c));
+        pts[k] = add(c, scale(d2, sph.radius));
+      } else {
+        double off = std::sqrt(sph.radius * sph.radius - da * da);
+        pts[k] = add(origins[k], scale(dirs[k], proj - off));
+      }
+      nrm[k] = normalize(sub(pts[k], c));
+    } else { pts[k] = rec.p; nrm[k] = rec.n; }
+  }
+  MVertex ch[kMneeMaxDepth];
+  int mat_id = sph.material_id;
+  ch[0] = {pts[0], nrm[0], 1.0 / m.refraction_index, mat_id};
+  ch[1] = {pts[1], neg(nrm[1]), m.refraction_index, mat_id};
+  return mnee_solve(s, sp, lp, ch, 2, throughput, tl);
+}
+// connect_to_light, mnee.hpp:73-88 (+ connect_to_light_seeded, :152-189)
+inline bool mnee_connect(const orc_scene& s, V3 sp, V3 lp, double& throughput, Tally& tl) {
+  if (mnee_straight(s, sp, lp, throughput, tl)) return true;
+  for (const rtx_sphere& sph : s.spheres) {
+    const rtx_material& m = s.mats[sph.material_id];
+    if (m.type != RTX_MAT_DIELECTRIC) continue;
+    V3 to_sphere = sub(mk(sph.center), sp), to_light = sub(lp, sp);
+    double ds = len(to_sphere), dl = len(to_light);
+    if (ds > dl + sph.radius) continue;
+    if (ds < sph.radius) continue;
+    V3 a = scale(to_sphere, 1.0 / ds), b = scale(to_light, 1.0 / dl);
+    if (dot(a, b) < 0.0) continue;
+    if (mnee_sphere_seed(s, sph, m, sp, lp, throughput, tl)) return true;
+  }
+  return false;
+}
+// MNEE::evaluate, mnee.hpp:632-763.  Returns whether any light contributed.
+template <class S>
+bool mnee_evaluate(const orc_scene& s, V3 hp, S& rng, V3& contribution, Tally& tl) {
+  contribution = {0, 0, 0};
+  bool any = false;
+  int j = 0;
+  for (const rtx_quad_light& q : s.quads) {
+    double u, v; rng.mnee_pair(j++, u, v);
+    V3 lp = add(mk(q.corner), add(scale(mk(q.edge_u), u), scale(mk(q.edge_v), v)));   // QuadLight::sample_point, primitives.hpp:258-262
+    V3 ln = mk(q.normal);
+    double w;
+    if (mnee_connect(s, hp, lp, w, tl)) {
+      V3 to_light = sub(lp, hp);
+      double d2 = len2(to_light);
+      V3 wil = normalize(neg(to_light));
+      double cl = std::fabs(dot(ln, wil));
+      double lpdf = d2 / (q.area * cl);
+      contribution = add(contribution, scale(mk(q.emission), w * cl / (d2 * lpdf)));
+      any = true;
+    }
+  }
+  for (const rtx_disk_light& dl : s.disks) {
+    double u, v; rng.mnee_pair(j++, u, v);
+    V3 lp = disk_sample_point(dl, u, v);
+    V3 ln = mk(dl.normal);
+    double w;
+    if (mnee_connect(s, hp, lp, w, tl)) {
+      V3 to_light = sub(lp, hp);
+      double d2 = len2(to_light);
+      V3 wil = normalize(neg(to_light));
+      double cl = std::fabs(dot(ln, wil));
+      double lpdf = d2 / (dl.area * cl);
+      contribution = add(contribution, scale(mk(dl.emission), w * cl / (d2 * lpdf)));
+      any = true;
+    }
+  }
+  for (int si : s.emissive_spheres) {   // spheres in index order whose material is emissive
+    const rtx_sphere& sph = s.spheres[si];
+    V3 to_sphere = sub(mk(sph.center), hp);
+    double dc = len(to_sphere);
+    V3 w3 = scale(to_sphere, 1.0 / dc);
+    double ctm = std::sqrt(1.0 - (sph.radius * sph.radius) / (dc * dc));
+    if (ctm < 0.0) ctm = 0.0;
+    double r1, r2; rng.mnee_pair(j++, r1, r2);
+    double ct = 1.0 + r1 * (ctm - 1.0);
+    double sn = std::sqrt(1.0 - ct * ct);
+    double phi = 2.0 * 3.14159265358979323846 * r2;
+    V3 uv = (std::fabs(w3.x) > 0.9) ? V3{0, 1, 0} : V3{1, 0, 0};
+    uv = normalize(cross(w3, uv));
+    V3 vv = cross(w3, uv);
+    V3 sd = add(scale(uv, sn * std::cos(phi)), add(scale(vv, sn * std::sin(phi)), scale(w3, ct)));
+    double t = dc * ct - std::sqrt(sph.radius * sph.radius - dc * dc * (1.0 - ct * ct));
+    V3 lp = add(hp, scale(sd, t));
+    V3 ln = normalize(sub(lp, mk(sph.center)));
+    double w;
+    if (mnee_connect(s, hp, lp, w, tl)) {
+      double solid = 2.0 * 3.14159265358979323846 * (1.0 - ctm);
+      double pdf = 1.0 / solid;
+      double cal = std::fabs(dot(ln, neg(sd)));
+      contribution = add(contribution, scale(mk(s.mats[sph.material_id].emission), w * cal / pdf));
+      any = true;
+    }
+  }
+  return any;
+}
+
 template <class S>
 V3 path_radiance(const orc_scene& s, const rtx_settings& st, Ray r, S& rng, Tally& tl) {
   V3 thr = {1.0, 1.0, 1.0}, acc = {0.0, 0.0, 0.0};
@@ -796,6 +1045,7 @@ V3 path_radiance(const orc_scene& s, const rtx_settings& st, Ray r, S& rng, Tall
     switch (m.type) {
       case RTX_MAT_LAMBERTIAN: {
         if (nee) {
+          bool skip_mnee = false;
           LightPick ls = sample_light(s, rec.p, rng);
           if (ls.valid) {
             bool is_env = ls.dist > 1e5;
@@ -821,8 +1071,16 @@ V3 path_radiance(const orc_scene& s, const rtx_settings& st, Ray r, S& rng, Tall
                   if (mis) w = power_heuristic(lps, bpl);
                   V3 direct = scale(mul(mul(ls.Le, surf), thr), cs / (kPi * lps) * w);
                   acc = add(acc, direct);
-                }
+                } else skip_mnee = true;   // `goto skip_nee` jumps over the MNEE block too (renderer.cpp:691, :695)
               }
+            }
+          }
+          if (st.use_mnee && !skip_mnee) {  // renderer.cpp:716-732
+            V3 mc;
+            if (mnee_evaluate(s, rec.p, rng, mc, tl)) {
+              V3 md = mul(mul(mc, surf), thr);
+              md = scale(md, 1.0 / 3.14159265358979323846);
+              acc = add(acc, md);
             }
           }
         }
@@ -994,7 +1252,6 @@ int orc_trace_closest(const orc_scene* s, const double* rays8, size_t n, rtx_hit
 int orc_render(const orc_scene* s, const rtx_camera* cam, const rtx_settings* st, int rng_mode, int threads,
                double* film, rtx_stats* stats) {
   if (!s || !cam || !st || !film) return RTX_ERR_INVALID_ARGUMENT;
-  if (st->use_mnee) return RTX_ERR_UNSUPPORTED;
   if (threads < 1) threads = 1;
   const int W = st->width, H = st->height;
   const int sc = st->shard_count > 0 ? st->shard_count : 1, si = st->shard_index;

@@ -31,7 +31,7 @@ int orc_bvh_dump(const orc_scene* s, double* boxes6, int32_t* node_ints4, int32_
 int orc_trace_closest(const orc_scene* s, const double* rays8, size_t n, rtx_hit* out, int threads);
 
 /* Renderer::render, PathTrace branch (engine/renderer.cpp:378-449) + ray_color_path
- * (engine/renderer.cpp:580-841) with use_mnee = false.  `film` receives width*height*3
+ * (engine/renderer.cpp:580-841), MNEE (engine/spectral/mnee.hpp) included when settings->use_mnee is set.  `film` receives width*height*3
  * UNCLAMPED linear doubles, pixel (x, y) at (y*width + x)*3, y = 0 at the bottom.
  * With ORC_RNG_MT19937 and threads = 1 the film equals the reference's bit for bit when
  * the reference generator is seeded with settings->seed. */

@@ -163,6 +163,22 @@ def make_post_fixtures():
     print("post fixtures", len(out) - 2)
 
 
+MNEE_FILMS = [("cornell_box", 24, 14, 3, 12, 91, 1, 1), ("cornell_box", 24, 14, 3, 12, 91, 1, 0), ("cornell_box_quad", 20, 20, 3, 12, 92, 1, 1),
+              ("caustics_test", 20, 20, 3, 12, 93, 1, 1), ("caustics_test", 20, 20, 3, 12, 93, 1, 0),
+              # kitchen_sink with MIS on: the quad-light look-ahead reads materials[-1] (see the films above) and here the
+              # garbage is large; disk_room: the straight probe of MNEE indexes materials[-1000] and the reference crashes
+              ("kitchen_sink", 24, 14, 3, 10, 94, 1, 0)]
+
+
+def make_mnee_fixtures():
+    """Seeded single-thread films with use_mnee = true (the CLI default of the reference)."""
+    for (n, W, H, spp, depth, seed, nee, mis) in MNEE_FILMS:
+        film, _ = ref_film(n, W, H, spp, depth, seed, nee, mis, mnee=1)
+        tag = f"{n}_{W}x{H}_s{spp}_d{depth}_seed{seed}_nee{nee}_mis{mis}_mnee1"
+        np.savez_compressed(os.path.join(HERE, "films", tag + ".npz"), film=film, scene=n, W=W, H=H, spp=spp, depth=depth, seed=seed, nee=nee, mis=mis, mnee=1)
+        print("film", tag, float(film.mean()))
+
+
 def rel_mse(x, r):
     x = np.clip(x, 0.0, 1.0); r = np.clip(r, 0.0, 1.0)   # the film Renderer::render returns is clamped
     return float(np.mean((x - r) ** 2 / (r ** 2 + 1e-2)))
@@ -173,6 +189,9 @@ def main():
         subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "ref"])
     for sub in ("loader", "hits", "bvh", "films", "converged", "kat"):
         os.makedirs(os.path.join(HERE, sub), exist_ok=True)
+    if "--mnee-only" in sys.argv:
+        make_mnee_fixtures()
+        return
     make_post_fixtures()
     if "--post-only" in sys.argv:
         return
@@ -215,6 +234,8 @@ def main():
         tag = f"{n}_{W}x{H}_s{spp}_d{depth}_seed{seed}_nee{nee}_mis{mis}"
         np.savez_compressed(os.path.join(HERE, "films", tag + ".npz"), film=film, scene=n, W=W, H=H, spp=spp, depth=depth, seed=seed, nee=nee, mis=mis)
         print("film", tag, float(film.mean()))
+
+    make_mnee_fixtures()
 
     # --- converged references + noise floor ----------------------------------------------
     for n, depth in (("cornell_box", 500), ("cornell_box_quad", 50), ("caustics_test", 16), ("environment_demo", 50), ("kitchen_sink", 24)):

@@ -119,13 +119,13 @@ def test_bvh_identical_to_reference_build(name, pkg, oracle, load_scene):
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "films", "*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
 def test_seeded_film_bit_exact(path, oracle, load_scene):
-    """Renderer::render + ray_color_path (engine/renderer.cpp:378-449, :580-841), use_mnee off:
-    same std::mt19937 seed, one thread => the same film, every bit."""
+    """Renderer::render + ray_color_path (engine/renderer.cpp:378-449, :580-841), with use_mnee off and on
+    (MNEE::evaluate, engine/spectral/mnee.hpp:632-763): same std::mt19937 seed, one thread => the same film, every bit."""
     fx = np.load(path)
     sd = load_scene(str(fx["scene"]))
     W, H = int(fx["W"]), int(fx["H"])
     st = sd.settings(width=W, height=H, samples_per_pixel=int(fx["spp"]), max_depth=int(fx["depth"]), seed=int(fx["seed"]),
-                     use_nee=int(fx["nee"]), use_mis=int(fx["mis"]))
+                     use_nee=int(fx["nee"]), use_mis=int(fx["mis"]), use_mnee=int(fx["mnee"]) if "mnee" in fx else 0)
     film, _ = oracle.OracleScene(sd).render(sd.camera(W, H), st, oracle.RNG_MT19937, threads=1)
     if len(sd.quad_lights) and int(fx["nee"]) and int(fx["mis"]):
         # When a BSDF ray lands on a quad light the reference's look-ahead reads materials[-1]
