@@ -35,7 +35,7 @@ typedef enum rtx_status {
   RTX_ERR_NO_DEVICE = -2,
   RTX_ERR_HIP = -3,
   RTX_ERR_NOT_READY = -4,      /* render before upload_scene / set_camera */
-  RTX_ERR_UNSUPPORTED = -5,    /* e.g. use_mnee = 1 */
+  RTX_ERR_UNSUPPORTED = -5,    /* e.g. use_mnee with the wavefront pipeline */
   RTX_ERR_OUT_OF_MEMORY = -6
 } rtx_status;
 
@@ -107,7 +107,7 @@ typedef struct rtx_settings {
   int32_t width, height;
   int32_t samples_per_pixel;
   int32_t max_depth;
-  int32_t use_nee, use_mis, use_mnee;      /* use_mnee != 0 -> RTX_ERR_UNSUPPORTED */
+  int32_t use_nee, use_mis, use_mnee;      /* use_mnee (Renderer::Settings::use_mnee, engine/renderer.hpp:101-133): renders in double precision, fused pipeline */
   int32_t use_background_gradient;
   double background_color[3], background_top[3], background_bottom[3];
   uint32_t seed;
@@ -128,6 +128,8 @@ typedef struct rtx_stats {
   double seconds_total;      /* wall time of the call */
   uint32_t kernel_launches;
   uint32_t pipeline_used;    /* RTX_PIPELINE_FUSED or _WAVEFRONT */
+  uint32_t precision_used;   /* RTX_PRECISION_*: use_mnee promotes a single-precision request to double */
+  uint32_t reserved_;
 } rtx_stats;
 
 /* One closest-hit result: the members of hit_record (core/hit.h:20-29) that identify the

@@ -86,7 +86,8 @@ class Settings(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("segments", C.c_uint64), ("seconds_render", C.c_double), ("seconds_main_kernel", C.c_double), ("seconds_total", C.c_double),
-                ("kernel_launches", C.c_uint32), ("pipeline_used", C.c_uint32)]
+                ("kernel_launches", C.c_uint32), ("pipeline_used", C.c_uint32),
+                ("precision_used", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class Hit(C.Structure):

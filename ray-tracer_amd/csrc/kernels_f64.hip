@@ -63,6 +63,17 @@ void launch_trace_ref(const DScene<double>& sc, const DSceneRef& ref, const doub
 int launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters,
                         const FusedLaunch& L, hipStream_t stream) {
   dim3 g(L.grid), b(kBlock);
+  if (L.mnee) {
+    if (L.mode == MODE_TREE && L.lds_mats)
+      hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE, true, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else if (L.mode == MODE_TREE_UV && L.lds_mats)
+      hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, true, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else if (!L.lds_mats && L.mode != MODE_FLAT)
+      hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, false, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else
+      return -1;
+    return 0;
+  }
   if (L.mode == MODE_TREE && L.lds_mats)
     hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
   else if (L.mode == MODE_TREE_UV && L.lds_mats)

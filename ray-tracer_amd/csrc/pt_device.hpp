@@ -1012,6 +1012,10 @@ template <class R> RTX_DEV void path_begin(PathState<R>& ps, const DCamera<R>& c
   ps.bounce_flags = F_ALIVE;
 }
 
+}  // namespace rtx
+#include "pt_mnee.hpp"
+namespace rtx {
+
 // What one vertex did, for the statistics: bit 0 = a shadow ray was cast, bit 1 = the vertex was shaded.
 enum : uint32_t { STEP_SHADOW = 1u, STEP_SHADED = 2u };
 
@@ -1020,9 +1024,12 @@ enum : uint32_t { STEP_SHADOW = 1u, STEP_SHADED = 2u };
 // the light sample is handed to `shadow(ray, t_max, contribution)`: the fused kernel traces it
 // on the spot, the wavefront pipeline queues it.  `mats` is the material table (an LDS copy when
 // the kernel staged one).
-template <class R, class ShadowFn>
-RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
-                             const DRenderParams& P, PathKey key, ShadowFn&& shadow) {
+// MNEE = true adds manifold next event estimation at Lambertian vertices (ref: engine/renderer.cpp:716-732);
+// it needs `shadow` to return whether the light sample was visible (the reference skips MNEE when an
+// unoccluded sample is rejected, :691/:695) and `trace`, a closest-hit functor (see pt_mnee.hpp).
+template <class R, bool MNEE, class ShadowFn, class TraceFn>
+RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, const Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
+                                  const DRenderParams& P, PathKey key, ShadowFn&& shadow, TraceFn&& trace) {
   const bool nee = P.use_nee != 0, mis = P.use_mis != 0;
   const bool env_is = sc.env.importance != 0;
   uint32_t did = 0;
@@ -1088,6 +1095,7 @@ RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec
 
   if (m.type == MAT_LAMBERTIAN) {
     if (nee) {  // ref: engine/renderer.cpp:654-714
+      bool skip_mnee = false;
       LightPick<R> ls = sample_light(sc, mats, rec.p, u16hi<R>(rn.z), u16hi<R>(rn.x), u16lo<R>(rn.x));
       if (ls.valid) {
         bool is_env = ls.dist > R(1e5);
@@ -1113,7 +1121,21 @@ RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec
             contrib = ((ls.Le * surf) * ps.thr) * (cs / (Consts<R>::pi * lps) * w);
           }
           Ray<R> sr = {rec.p, ldir};
-          shadow(sr, is_env ? R(1e9) : (ldist - R(0.001)), contrib);
+          if constexpr (MNEE) {
+            const bool visible = shadow(sr, is_env ? R(1e9) : (ldist - R(0.001)), contrib);
+            if (visible && !(ok && lps > R(0))) skip_mnee = true;   // `goto skip_nee`, ref: renderer.cpp:691, :695
+          } else {
+            shadow(sr, is_env ? R(1e9) : (ldist - R(0.001)), contrib);
+          }
+        }
+      }
+      if constexpr (MNEE) {
+        if (!skip_mnee) {
+          V3<R> mc;
+          if (mnee_evaluate(sc, mats, rec.p, key, bounce, mc, trace)) {
+            V3<R> md = ((mc * surf) * ps.thr) * (R(1) / R(3.14159265358979323846));
+            ps.acc = ps.acc + md;
+          }
         }
       }
     }
@@ -1161,13 +1183,29 @@ RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec
   return did;
 }
 
-// Fused form: trace, shade, and trace the shadow ray in place.
-template <class R, int MODE> RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMaterial<R>* mats, const DRenderParams& P, PathKey key, LaneStack st) {
+template <class R, class ShadowFn>
+RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
+                             const DRenderParams& P, PathKey key, ShadowFn&& shadow) {
+  return path_vertex_impl<R, false>(ps, hit, rec, sc, mats, P, key, shadow, [](const Ray<R>&, R, R, Hit<R>&) { return false; });
+}
+
+// Fused form: trace, shade, and trace the shadow ray in place.  `extra_traces` counts the
+// closest-hit queries MNEE makes.
+template <class R, int MODE, bool MNEE = false>
+RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMaterial<R>* mats, const DRenderParams& P, PathKey key, LaneStack st, uint32_t& extra_traces) {
   Hit<R> rec;
   const bool hit = trace_closest<R, MODE>(sc, ps.ray, R(0.001), R(1e9), rec, st);
-  return path_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<R>& sr, R t_max, V3<R> contrib) {
-    if (!trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st)) ps.acc = ps.acc + contrib;
-  });
+  return path_vertex_impl<R, MNEE>(
+      ps, hit, rec, sc, mats, P, key,
+      [&](const Ray<R>& sr, R t_max, V3<R> contrib) {
+        const bool visible = !trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st);
+        if (visible) ps.acc = ps.acc + contrib;
+        return visible;
+      },
+      [&](const Ray<R>& r, R t_min, R t_max, Hit<R>& h) {
+        ++extra_traces;
+        return trace_closest<R, MODE>(sc, r, t_min, t_max, h, st);
+      });
 }
 
 }  // namespace rtx

@@ -152,7 +152,6 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   if (s->width <= 0 || s->height <= 0 || s->samples_per_pixel <= 0 || s->max_depth < 0)
     return fail(RTX_ERR_INVALID_ARGUMENT, "bad settings: %dx%d spp=%d depth=%d", s->width, s->height, s->samples_per_pixel, s->max_depth);
   if (s->width > 65535 || s->height > 65535) return fail(RTX_ERR_INVALID_ARGUMENT, "film too large (max 65535 per side)");
-  if (s->use_mnee) return fail(RTX_ERR_UNSUPPORTED, "use_mnee: manifold next-event estimation is not implemented by this backend");
   const int sc_n = s->shard_count > 0 ? s->shard_count : 1;
   if (s->shard_index < 0 || s->shard_index >= sc_n) return fail(RTX_ERR_INVALID_ARGUMENT, "shard %d of %d", s->shard_index, sc_n);
   if (s->precision != RTX_PRECISION_F32 && s->precision != RTX_PRECISION_F64) return fail(RTX_ERR_INVALID_ARGUMENT, "precision %d", s->precision);
@@ -180,13 +179,17 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   rtx_stats st;
   memset(&st, 0, sizeof st);
   if (npix == 0) { if (stats) *stats = st; return RTX_OK; }
-  const bool f64 = s->precision == RTX_PRECISION_F64;
+  // Manifold next event estimation runs in the double-precision fused kernel only (its Newton solver's
+  // tolerances leave no room for single precision): a single-precision request is promoted.
+  const bool mnee = s->use_mnee != 0 && s->use_nee != 0;
+  const bool f64 = s->precision == RTX_PRECISION_F64 || mnee;
   const bool f64_req = f64;
   // AUTO: scenes that walk a tree run the queue-based pipeline (its traversal kernels hold 2-4x
   // the waves of the fused kernel, measured 1.6x faster on a 10 M-triangle scene); scenes small
   // enough for the linear / flat intersection stay fused (no queue traffic, measured 2-3x faster).
   int pipeline = s->pipeline;
   if (pipeline == RTX_PIPELINE_AUTO) pipeline = (!f64_req && c->scene.n_prims > kLinearMaxPrims) ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED;
+  if (pipeline == RTX_PIPELINE_WAVEFRONT && mnee) return fail(RTX_ERR_UNSUPPORTED, "use_mnee is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && f64) return fail(RTX_ERR_UNSUPPORTED, "the wavefront pipeline is single precision only");
 
   float* d_film = (float*)dev_out;
@@ -206,6 +209,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     if (!c->partial.ensure((size_t)items * 3 * elem)) return fail(RTX_ERR_OUT_OF_MEMORY, "chunk-sum buffer (%llu bytes)", (unsigned long long)(items * 3 * elem));
     FusedLaunch L;
     L.mode = c->scene.fused_mode(f64);
+    L.mnee = mnee;
     const size_t mat_bytes = (size_t)c->scene.dev_f.n_mats * (f64 ? sizeof(DMaterial<double>) : sizeof(DMaterial<float>));
     L.lds_mats = mat_bytes <= kMaxLdsMaterialBytes;
     if (!L.lds_mats) L.mode = MODE_TREE_UV;
@@ -247,6 +251,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   st.seconds_main_kernel = ms * 1e-3;
   st.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
   st.pipeline_used = (uint32_t)pipeline;
+  st.precision_used = f64 ? RTX_PRECISION_F64 : RTX_PRECISION_F32;
   if (stats) *stats = st;
   return RTX_OK;
 }

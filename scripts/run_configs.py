@@ -35,7 +35,7 @@ def main():
                 t0 = time.time(); pt.upload_scene(sd); t_upload = time.time() - t0
                 info = pt.bvh_info() if hasattr(pt, "bvh_info") else None
                 pt.set_camera(sd.camera(over["width"], over["height"]))
-                pt.set_settings(sd.settings(use_nee=1, use_mis=1, use_mnee=0, pipeline=pipe, **over))
+                pt.set_settings(sd.settings(use_nee=1, use_mis=1, use_mnee=int('--mnee' in sys.argv), pipeline=pipe, **over))
                 best = None
                 for _ in range(repeat):
                     film = pt.render(); st = pt.last_stats
@@ -43,7 +43,7 @@ def main():
                 st = best
                 rays = st.rays_closest + st.rays_shadow
                 print(json.dumps({
-                    "config": cfg, "scene": name, **over, "pipeline_used": {1: "fused", 2: "wavefront"}.get(st.pipeline_used, st.pipeline_used),
+                    "config": cfg, "scene": name, **over, "pipeline_used": {1: "fused", 2: "wavefront"}.get(st.pipeline_used, st.pipeline_used), "precision_used": {0: "f32", 1: "f64"}.get(st.precision_used), "mnee": int("--mnee" in sys.argv),
                     "ms_render": round(st.seconds_render * 1e3, 3), "ms_main_kernels": round(st.seconds_main_kernel * 1e3, 3),
                     "msamples_per_s": round(st.samples / st.seconds_render / 1e6, 2), "mrays_per_s": round(rays / st.seconds_render / 1e6, 2),
                     "segments_per_sample": round(st.segments / st.samples, 3), "shadow_per_sample": round(st.rays_shadow / st.samples, 3),

@@ -21,6 +21,23 @@ def pkg():
     return rtx_pkg.load()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_device_first(request):
+    """On a GPU box, let torch create its HIP context before the library's first kernel: a few tests hand torch
+    tensors to the library, and torch's lazy initialisation was seen to fail ("No HIP GPUs are available") when it
+    came after a long series of the library's own launches in the same process."""
+    markexpr = request.config.getoption("-m", default="") or ""
+    if "not gpu" in markexpr:
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_py

@@ -117,6 +117,37 @@ def test_f64_film_equals_oracle(name, nee, mis, pkg, oracle, tracer, load_scene)
     assert abs(got.mean() - ref.mean()) < mean_tol * (1 + ref.mean())
 
 
+@pytest.mark.parametrize("name,mis", [("cornell_box", 1), ("cornell_box", 0), ("cornell_box_quad", 1), ("caustics_test", 1), ("kitchen_sink", 0), ("disk_room", 1)])
+def test_mnee_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
+    """use_mnee = 1 (the reference's CLI default; MNEE::evaluate, engine/spectral/mnee.hpp:632-763): the render is
+    promoted to the double-precision fused kernel and agrees with the oracle run on the same counter-based random
+    numbers.  The oracle's MNEE equals the real reference's bit for bit (test_seeded_film_bit_exact).  A Newton solve
+    may stop one iteration earlier or later on a last-bit difference; those pixels are bounded."""
+    sd = load_scene(name)
+    W, H, spp = 40, 24, 6
+    over = dict(width=W, height=H, samples_per_pixel=spp, max_depth=min(sd.max_depth, 12), seed=47, use_nee=1, use_mis=mis, use_mnee=1)
+    ref, ost = oracle.OracleScene(sd).render(sd.camera(W, H), sd.settings(**over), oracle.RNG_COUNTER, threads=16)
+    off, _ = oracle.OracleScene(sd).render(sd.camera(W, H), sd.settings(**dict(over, use_mnee=0)), oracle.RNG_COUNTER, threads=16)
+    pt = tracer(sd)
+    pt.set_camera(sd.camera(W, H))
+    pt.set_settings(sd.settings(precision=pkg.abi.PRECISION_F32, **over))
+    got = pt.render().astype(np.float64)
+    st = pt.last_stats
+    assert st.precision_used == pkg.abi.PRECISION_F64 and st.pipeline_used == pkg.abi.PIPELINE_FUSED
+    if name == "kitchen_sink":   # its checker floor flips a sample now and then (see test_f64_film_equals_oracle)
+        assert st.samples == W * H * spp and abs(int(st.rays_shadow) - int(ost.rays_shadow)) <= 0.005 * ost.rays_shadow
+    else:
+        assert st.samples == W * H * spp and st.rays_shadow == ost.rays_shadow and st.segments == ost.segments
+    # (closest-hit counts differ by construction: the oracle traces the MIS look-ahead ray twice, as the reference does)
+    assert abs(int(st.rays_closest) - int(ost.rays_closest)) <= 0.05 * ost.rays_closest
+    bad = (np.abs(got - ref) > 1e-5 * (1.0 + np.abs(ref))).any(axis=2)
+    limit = 0.03 if name == "kitchen_sink" else 0.01
+    assert bad.mean() < limit, (bad.mean(), np.abs(got - ref).max())
+    assert abs(got.mean() - ref.mean()) < 2e-3 * (1 + ref.mean())
+    if name in ("cornell_box", "caustics_test"):
+        assert np.abs(ref - off).max() > 1e-3   # MNEE does contribute in these scenes
+
+
 @pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "caustics_test", "environment_demo"])
 def test_f32_film_within_tolerance_of_reference(name, pkg, tracer, load_scene):
     """Converged-image criterion: relMSE(GPU @ N spp vs reference @ 4N spp) <= 1.25 x
@@ -212,7 +243,7 @@ def test_error_paths(pkg, load_scene):
         with pytest.raises(abi.RtxError, match="set_camera"):
             pt.render()
         pt.set_camera(sd.camera(8, 8))
-        pt.set_settings(sd.settings(width=8, height=8, samples_per_pixel=1, use_mnee=1))
+        pt.set_settings(sd.settings(width=8, height=8, samples_per_pixel=1, use_mnee=1, pipeline=abi.PIPELINE_WAVEFRONT))
         with pytest.raises(abi.RtxError, match="mnee"):
             pt.render()
         pt.set_settings(sd.settings(width=8, height=8, samples_per_pixel=0))
