@@ -100,6 +100,10 @@ typedef struct rtx_camera { double origin[3], lower_left_corner[3], horizontal[3
 
 enum { RTX_PRECISION_F32 = 0, RTX_PRECISION_F64 = 1 };
 enum { RTX_PIPELINE_AUTO = 0, RTX_PIPELINE_FUSED = 1, RTX_PIPELINE_WAVEFRONT = 2 };
+/* RenderMode (engine/renderer.hpp:26-34), the two modes this backend implements, with the reference's values:
+ * Whitted = Renderer::ray_color_whitted (engine/renderer.cpp:483-569), PathTrace = ray_color_path (:580-841).
+ * Any other value returns RTX_ERR_UNSUPPORTED. */
+enum { RTX_MODE_WHITTED = 0, RTX_MODE_PATHTRACE = 1 };
 
 /* Renderer::Settings (engine/renderer.hpp:101-133), PathTrace mode members, plus what a
  * GPU backend needs in addition (seed, precision, pipeline, row sharding). */
@@ -116,6 +120,8 @@ typedef struct rtx_settings {
   /* Row sharding: this context renders rows y with  y % shard_count == shard_index.
    * shard_count = 1 renders the whole film. */
   int32_t shard_index, shard_count;
+  int32_t mode;                             /* RTX_MODE_* (Renderer::Settings::mode); Whitted runs in the fused pipeline */
+  int32_t reserved_;
 } rtx_settings;
 
 typedef struct rtx_stats {

@@ -1146,6 +1146,59 @@ V3 path_radiance(const orc_scene& s, const rtx_settings& st, Ray r, S& rng, Tall
   return acc;
 }
 
+// Renderer::ray_color_whitted — engine/renderer.cpp:483-569 (recursive, as the reference; `level` counts
+// the recursion depth for the counter-based sampler)
+template <class S>
+V3 whitted_radiance(const orc_scene& s, const rtx_settings& st, Ray r, int depth, int level, S& rng, Tally& tl) {
+  if (depth <= 0) return {0, 0, 0};
+  rng.begin_bounce(level);
+  Hit rec;
+  tl.closest++;
+  if (scene_hit(s, r, 0.001, 1e9, rec)) {
+    tl.segments++;
+    if (rec.mat >= 0) {   // a quad / disk light hit indexes materials[negative] in the reference (undefined); defined as a miss
+      const rtx_material& m = s.mats[rec.mat];
+      V3 surf = albedo_at(s, m, rec.p, rec.u, rec.v);
+      switch (m.type) {
+        case RTX_MAT_LAMBERTIAN: {
+          V3 direct = {0, 0, 0};
+          for (const rtx_point_light& pl : s.points) {
+            V3 to_light = sub(mk(pl.position), rec.p);   // Scene::is_shadowed, scene.hpp:554-564: unnormalised direction, t up to |to_light|
+            double distance = len(to_light);
+            Hit sh;
+            tl.shadow++;
+            if (!scene_hit(s, Ray{rec.p, to_light}, 0.001, distance, sh)) {
+              V3 ldir = normalize(sub(mk(pl.position), rec.p));
+              double diffuse = std::fmax(0.0, dot(rec.n, ldir));
+              direct = add(direct, scale(mk(pl.intensity), diffuse));
+            }
+          }
+          V3 sdir = add(rec.n, rng.unit_vector());
+          if (len2(sdir) < 1e-8) sdir = rec.n;
+          V3 indirect = whitted_radiance(s, st, Ray{rec.p, sdir}, depth - 1, level + 1, rng, tl);
+          return mul(surf, add(direct, indirect));
+        }
+        case RTX_MAT_METAL: {
+          V3 refl = reflect(normalize(r.d), rec.n);
+          if (dot(refl, rec.n) > 0) return mul(surf, whitted_radiance(s, st, Ray{rec.p, refl}, depth - 1, level + 1, rng, tl));
+          return {0, 0, 0};
+        }
+        case RTX_MAT_DIELECTRIC: {
+          double ratio = rec.front ? (1.0 / m.refraction_index) : m.refraction_index;
+          V3 ud = normalize(r.d);
+          double ct = std::fmin(dot(neg(ud), rec.n), 1.0);
+          double sn = std::sqrt(1.0 - ct * ct);
+          V3 dir;
+          if (ratio * sn > 1.0 || schlick(ct, ratio) > rng.fresnel()) dir = reflect(ud, rec.n);
+          else dir = refract(ud, rec.n, ratio);
+          return mul(V3{1.0, 1.0, 1.0}, whitted_radiance(s, st, Ray{rec.p, dir}, depth - 1, level + 1, rng, tl));
+        }
+      }
+    }
+  }
+  return background(s, st, r);
+}
+
 inline Ray camera_ray(const rtx_camera& c, double s, double t) {  // scene.hpp:99-108
   V3 o = mk(c.origin);
   V3 d = sub(add(add(mk(c.lower_left_corner), scale(mk(c.horizontal), s)), scale(mk(c.vertical), t)), o);
@@ -1161,7 +1214,7 @@ void render_rows(const orc_scene& s, const rtx_camera& cam, const rtx_settings& 
       double u = ((double)x + rng.jitter_x()) / st.width;
       double v = ((double)y + rng.jitter_y()) / st.height;
       Ray r = camera_ray(cam, u, v);
-      px = add(px, path_radiance(s, st, r, rng, tl));
+      px = add(px, st.mode == RTX_MODE_WHITTED ? whitted_radiance(s, st, r, st.max_depth, 0, rng, tl) : path_radiance(s, st, r, rng, tl));
     }
     px = scale(px, 1.0 / st.samples_per_pixel);
     double* o = film + ((size_t)y * st.width + x) * 3;

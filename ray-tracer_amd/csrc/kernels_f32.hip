@@ -17,6 +17,13 @@ void launch_selftest(float* out, int n, hipStream_t stream) {
 int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
                         const FusedLaunch& L, hipStream_t stream) {
   dim3 g(L.grid), b(kBlock);
+  if (L.integ == INTEG_WHITTED) {   // the Whitted integrator exists for the general (TREE_UV) instances only
+    if (L.mode != MODE_TREE_UV) return -1;
+    if (L.lds_mats) hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, true, INTEG_WHITTED>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, false, INTEG_WHITTED>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    return 0;
+  }
+  if (L.integ != INTEG_PATH) return -1;
   if (L.mode == MODE_FLAT && L.lds_mats)
     hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
   else if (L.mode == MODE_TREE && L.lds_mats)

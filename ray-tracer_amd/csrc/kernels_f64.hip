@@ -63,15 +63,21 @@ void launch_trace_ref(const DScene<double>& sc, const DSceneRef& ref, const doub
 int launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters,
                         const FusedLaunch& L, hipStream_t stream) {
   dim3 g(L.grid), b(kBlock);
-  if (L.mnee) {
+  if (L.integ == INTEG_PATH_MNEE) {
     if (L.mode == MODE_TREE && L.lds_mats)
-      hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE, true, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+      hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE, true, INTEG_PATH_MNEE>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     else if (L.mode == MODE_TREE_UV && L.lds_mats)
-      hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, true, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+      hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, true, INTEG_PATH_MNEE>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     else if (!L.lds_mats && L.mode != MODE_FLAT)
-      hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, false, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+      hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, false, INTEG_PATH_MNEE>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     else
       return -1;
+    return 0;
+  }
+  if (L.integ == INTEG_WHITTED) {   // the Whitted integrator exists for the general (TREE_UV) instances only
+    if (L.mode != MODE_TREE_UV) return -1;
+    if (L.lds_mats) hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, true, INTEG_WHITTED>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, false, INTEG_WHITTED>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     return 0;
   }
   if (L.mode == MODE_TREE && L.lds_mats)

@@ -1189,23 +1189,83 @@ RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec
   return path_vertex_impl<R, false>(ps, hit, rec, sc, mats, P, key, shadow, [](const Ray<R>&, R, R, Hit<R>&) { return false; });
 }
 
-// Fused form: trace, shade, and trace the shadow ray in place.  `extra_traces` counts the
-// closest-hit queries MNEE makes.
-template <class R, int MODE, bool MNEE = false>
-RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMaterial<R>* mats, const DRenderParams& P, PathKey key, LaneStack st, uint32_t& extra_traces) {
+// Renderer::ray_color_whitted (ref: engine/renderer.cpp:483-569) unrolled into one vertex per call:
+// the recursion  c * (direct + L(child))  becomes  acc += thr * c * direct;  thr *= c.  `occluded(ray, t_max)`
+// answers Scene::is_shadowed (ref: engine/scene.hpp:554-564).  Returns STEP_* and adds the number of shadow
+// queries to `n_shadow`.
+template <class R, class OccFn>
+RTX_DEV uint32_t whitted_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
+                                const DRenderParams& P, PathKey key, OccFn&& occluded, uint32_t& n_shadow) {
+  const int bounce = (int)(ps.bounce_flags >> 4);
+  if (bounce >= P.max_depth) { ps.bounce_flags = 0; return 0u; }   // depth <= 0: black
+  // a quad / disk light has a negative material id; the reference indexes its material array with it
+  // (undefined behaviour, renderer.cpp:493) — defined here as "no hit"
+  if (!hit || rec.mat < 0) {
+    ps.acc = ps.acc + ps.thr * background(sc, P, ps.ray);
+    ps.bounce_flags = 0;
+    return hit ? STEP_SHADED : 0u;
+  }
+  const DMaterial<R>& m = mats[rec.mat];
+  const V3<R> surf = albedo_at(sc, m, rec);
+  const U4 rn = philox4x32_10(key.sample, 1u + (uint32_t)bounce, key.pixel, key.seed);
+  V3<R> dir;
+  if (m.type == MAT_LAMBERTIAN) {
+    V3<R> direct = {R(0), R(0), R(0)};
+    for (int i = 0; i < sc.n_points; ++i) {
+      const V3<R> lpos = mk3(sc.points[i].pos);
+      const V3<R> to_light = lpos - rec.p;   // unnormalised direction with t up to |to_light|, as the reference does
+      const R distance = len(to_light);
+      ++n_shadow;
+      Ray<R> sr = {rec.p, to_light};
+      if (!occluded(sr, distance)) {
+        const R diffuse = max_(R(0), dot(rec.n, normalize(lpos - rec.p)));
+        direct = direct + mk3(sc.points[i].I) * diffuse;
+      }
+    }
+    ps.acc = ps.acc + ps.thr * (surf * direct);
+    ps.thr = ps.thr * surf;
+    dir = rec.n + unit_vector(u16hi<R>(rn.y), u16lo<R>(rn.y));
+    if (len2(dir) < R(1e-8)) dir = rec.n;
+  } else if (m.type == MAT_METAL) {
+    dir = reflect(normalize(ps.ray.d), rec.n);
+    if (!(dot(dir, rec.n) > R(0))) { ps.bounce_flags = 0; return STEP_SHADED; }
+    ps.thr = ps.thr * surf;
+  } else {
+    R ratio = rec.front ? (R(1) / m.ior) : m.ior;
+    V3<R> ud = normalize(ps.ray.d);
+    R ct = min_(dot(-ud, rec.n), R(1));
+    R sn = sqrt_(R(1) - ct * ct);
+    if (ratio * sn > R(1) || schlick(ct, ratio) > u16hi<R>(rn.w)) dir = reflect(ud, rec.n);
+    else dir = refract(ud, rec.n, ratio);
+  }
+  ps.ray.o = rec.p;
+  ps.ray.d = dir;
+  ps.bounce_flags = (bounce + 1 >= P.max_depth) ? 0u : ((((uint32_t)(bounce + 1)) << 4) | F_ALIVE);   // depth <= 0 returns black
+  return STEP_SHADED;
+}
+
+// Fused form: trace, shade, and trace the shadow ray(s) in place.  `extra_traces` counts the closest-hit
+// queries MNEE makes, `extra_shadow` the shadow queries of the Whitted integrator.
+template <class R, int MODE, int INTEG = INTEG_PATH>
+RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMaterial<R>* mats, const DRenderParams& P, PathKey key, LaneStack st, uint32_t& extra_traces,
+                           uint32_t& extra_shadow) {
   Hit<R> rec;
   const bool hit = trace_closest<R, MODE>(sc, ps.ray, R(0.001), R(1e9), rec, st);
-  return path_vertex_impl<R, MNEE>(
-      ps, hit, rec, sc, mats, P, key,
-      [&](const Ray<R>& sr, R t_max, V3<R> contrib) {
-        const bool visible = !trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st);
-        if (visible) ps.acc = ps.acc + contrib;
-        return visible;
-      },
-      [&](const Ray<R>& r, R t_min, R t_max, Hit<R>& h) {
-        ++extra_traces;
-        return trace_closest<R, MODE>(sc, r, t_min, t_max, h, st);
-      });
+  if constexpr (INTEG == INTEG_WHITTED) {
+    return whitted_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<R>& sr, R t_max) { return trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st); }, extra_shadow);
+  } else {
+    return path_vertex_impl<R, INTEG == INTEG_PATH_MNEE>(
+        ps, hit, rec, sc, mats, P, key,
+        [&](const Ray<R>& sr, R t_max, V3<R> contrib) {
+          const bool visible = !trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st);
+          if (visible) ps.acc = ps.acc + contrib;
+          return visible;
+        },
+        [&](const Ray<R>& r, R t_min, R t_max, Hit<R>& h) {
+          ++extra_traces;
+          return trace_closest<R, MODE>(sc, r, t_min, t_max, h, st);
+        });
+  }
 }
 
 }  // namespace rtx

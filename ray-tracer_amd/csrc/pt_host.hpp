@@ -54,7 +54,7 @@ struct FusedLaunch {
   int grid;
   size_t lds_bytes;     // dynamic LDS per workgroup
   int stack_first_int;  // offset (in ints) of the traversal stacks inside the dynamic LDS
-  bool mnee = false;    // manifold next event estimation at Lambertian vertices (double precision only)
+  int integ = INTEG_PATH;  // INTEG_*: path tracing, path tracing with MNEE (double precision only), Whitted (TREE_UV instances only)
 };
 int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
                         const FusedLaunch& L, hipStream_t stream);

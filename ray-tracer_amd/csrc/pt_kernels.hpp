@@ -50,7 +50,7 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #ifndef RTX_FLAT_MIN_WAVES
 #define RTX_FLAT_MIN_WAVES 4
 #endif
-template <class R, int MODE, bool LDS_MATS, bool MNEE = false>
+template <class R, int MODE, bool LDS_MATS, int INTEG = INTEG_PATH>
 __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? RTX_FLAT_MIN_WAVES : 1)) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
                                                                DCounters* __restrict__ counters, int stack_first_int) {
   const DMaterial<R>* mats = sc.mats;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? RTX_FLAT_MIN_WAVES : 1
   // that leaves the loop stops adding, so the lane that stays longest holds the wave's totals:
   // they are recovered with a max over the lanes at the end.
   uint32_t w_steps = 0, w_shadow = 0, w_shaded = 0, w_samples = 0;
-  uint32_t extra_traces = 0;   // per lane: closest-hit queries made by MNEE
+  uint32_t extra_traces = 0, extra_shadow = 0;   // per lane: closest-hit queries made by MNEE, shadow queries of the Whitted integrator
   PathState<R> ps;
   ps.bounce_flags = 0;
   V3<R> sum = {R(0), R(0), R(0)};
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? RTX_FLAT_MIN_WAVES : 1
   w_samples += (uint32_t)__popcll(__ballot(active));
   while (active) {
     w_steps += (uint32_t)__popcll(__ballot(1));
-    const uint32_t did = path_step<R, MODE, MNEE>(ps, sc, mats, P, key, st, extra_traces);
+    const uint32_t did = path_step<R, MODE, INTEG>(ps, sc, mats, P, key, st, extra_traces, extra_shadow);
     w_shadow += (uint32_t)__popcll(__ballot((did & STEP_SHADOW) != 0));
     w_shaded += (uint32_t)__popcll(__ballot((did & STEP_SHADED) != 0));
     bool started = false;
@@ -114,10 +114,14 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? RTX_FLAT_MIN_WAVES : 1
     w_samples += (uint32_t)__popcll(__ballot(started));   // outside the divergent branch: counters must be added in uniform flow
   }
   w_samples = wave_max(w_samples); w_steps = wave_max(w_steps); w_shadow = wave_max(w_shadow); w_shaded = wave_max(w_shaded);
-  if constexpr (MNEE) {
+  if constexpr (INTEG != INTEG_PATH) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) extra_traces += (uint32_t)__shfl_xor((int)extra_traces, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+      extra_traces += (uint32_t)__shfl_xor((int)extra_traces, off, 64);
+      extra_shadow += (uint32_t)__shfl_xor((int)extra_shadow, off, 64);
+    }
     w_steps += extra_traces;
+    w_shadow += extra_shadow;
   }
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&counters->samples, (unsigned long long)w_samples);

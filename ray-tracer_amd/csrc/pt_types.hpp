@@ -99,6 +99,8 @@ constexpr int kStackDepth = 48;      // per-lane traversal stack entries (LDS)
 
 // How a kernel instance intersects (see pt_device.hpp).
 enum { MODE_TREE = 0, MODE_TREE_UV = 1, MODE_FLAT = 2 };
+// Integrator a fused kernel instance runs: ray_color_path, ray_color_path with MNEE, ray_color_whitted.
+enum { INTEG_PATH = 0, INTEG_PATH_MNEE = 1, INTEG_WHITTED = 2 };
 constexpr int kFlatMaxSpheres = 16;   // flat mode: sphere-only bounded primitives, at most this many
 constexpr size_t kMaxLdsMaterialBytes = 32768;
 

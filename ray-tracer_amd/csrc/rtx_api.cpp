@@ -156,6 +156,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   if (s->shard_index < 0 || s->shard_index >= sc_n) return fail(RTX_ERR_INVALID_ARGUMENT, "shard %d of %d", s->shard_index, sc_n);
   if (s->precision != RTX_PRECISION_F32 && s->precision != RTX_PRECISION_F64) return fail(RTX_ERR_INVALID_ARGUMENT, "precision %d", s->precision);
   if (s->pipeline < RTX_PIPELINE_AUTO || s->pipeline > RTX_PIPELINE_WAVEFRONT) return fail(RTX_ERR_INVALID_ARGUMENT, "pipeline %d", s->pipeline);
+  if (s->mode != RTX_MODE_WHITTED && s->mode != RTX_MODE_PATHTRACE) return fail(RTX_ERR_UNSUPPORTED, "render mode %d: only Whitted (0) and PathTrace (1) are implemented", s->mode);
   if (!host_out && !dev_out) return fail(RTX_ERR_INVALID_ARGUMENT, "output buffer is NULL");
   HIP_TRY(hipSetDevice(c->device));
   auto wall0 = std::chrono::steady_clock::now();
@@ -181,14 +182,16 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   if (npix == 0) { if (stats) *stats = st; return RTX_OK; }
   // Manifold next event estimation runs in the double-precision fused kernel only (its Newton solver's
   // tolerances leave no room for single precision): a single-precision request is promoted.
-  const bool mnee = s->use_mnee != 0 && s->use_nee != 0;
+  const bool whitted = s->mode == RTX_MODE_WHITTED;
+  const bool mnee = !whitted && s->use_mnee != 0 && s->use_nee != 0;
   const bool f64 = s->precision == RTX_PRECISION_F64 || mnee;
   const bool f64_req = f64;
   // AUTO: scenes that walk a tree run the queue-based pipeline (its traversal kernels hold 2-4x
   // the waves of the fused kernel, measured 1.6x faster on a 10 M-triangle scene); scenes small
   // enough for the linear / flat intersection stay fused (no queue traffic, measured 2-3x faster).
   int pipeline = s->pipeline;
-  if (pipeline == RTX_PIPELINE_AUTO) pipeline = (!f64_req && c->scene.n_prims > kLinearMaxPrims) ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED;
+  if (pipeline == RTX_PIPELINE_AUTO) pipeline = (!f64_req && !whitted && c->scene.n_prims > kLinearMaxPrims) ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED;
+  if (pipeline == RTX_PIPELINE_WAVEFRONT && whitted) return fail(RTX_ERR_UNSUPPORTED, "the Whitted mode is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && mnee) return fail(RTX_ERR_UNSUPPORTED, "use_mnee is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && f64) return fail(RTX_ERR_UNSUPPORTED, "the wavefront pipeline is single precision only");
 
@@ -208,8 +211,8 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     if (items >= 0x7fffffffull) return fail(RTX_ERR_INVALID_ARGUMENT, "film too large for one launch (%llu work items)", items);
     if (!c->partial.ensure((size_t)items * 3 * elem)) return fail(RTX_ERR_OUT_OF_MEMORY, "chunk-sum buffer (%llu bytes)", (unsigned long long)(items * 3 * elem));
     FusedLaunch L;
-    L.mode = c->scene.fused_mode(f64);
-    L.mnee = mnee;
+    L.mode = whitted ? MODE_TREE_UV : c->scene.fused_mode(f64);
+    L.integ = whitted ? INTEG_WHITTED : mnee ? INTEG_PATH_MNEE : INTEG_PATH;
     const size_t mat_bytes = (size_t)c->scene.dev_f.n_mats * (f64 ? sizeof(DMaterial<double>) : sizeof(DMaterial<float>));
     L.lds_mats = mat_bytes <= kMaxLdsMaterialBytes;
     if (!L.lds_mats) L.mode = MODE_TREE_UV;

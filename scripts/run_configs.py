@@ -1,4 +1,4 @@
-"""Runs the measurement configurations C2-C5 once each on cuda:0 and prints one JSON line per run.
+"""Runs the measurement configurations C1-C5 once each on cuda:0 and prints one JSON line per run.
 
   python scripts/run_configs.py [c2 c3 c4 c5 ...] [--repeat N]
 C4 at its full 3840x2160x4096 size takes several seconds per scene; C5 builds a 10 M triangle scene."""
@@ -11,6 +11,7 @@ pkg = rtx_pkg.load(); abi = pkg.abi
 SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 
 CONFIGS = {
+    "c1": [("demo", dict(width=2560, height=1440, samples_per_pixel=64, max_depth=50, mode=0))],   # the scene file's own mode: Whitted
     "c2": [("cornell_box", dict(width=1920, height=1080, samples_per_pixel=1024, max_depth=500))],
     "c3": [("cornell_box_quad", dict(width=800, height=800, samples_per_pixel=128, max_depth=50)),
            ("caustics_test", dict(width=800, height=800, samples_per_pixel=128, max_depth=16))],
@@ -25,7 +26,7 @@ def main():
     repeat = int(sys.argv[sys.argv.index("--repeat") + 1]) if "--repeat" in sys.argv else 2
     pipes = {"auto": abi.PIPELINE_AUTO, "fused": abi.PIPELINE_FUSED, "wavefront": abi.PIPELINE_WAVEFRONT}
     pipe = pipes[sys.argv[sys.argv.index("--pipeline") + 1]] if "--pipeline" in sys.argv else abi.PIPELINE_AUTO
-    for cfg in (args or ["c2", "c3", "c4", "c5"]):
+    for cfg in (args or ["c1", "c2", "c3", "c4", "c5"]):
         for name, over in CONFIGS[cfg]:
             if spp: over = dict(over, samples_per_pixel=spp)
             t0 = time.time()

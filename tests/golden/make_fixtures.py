@@ -120,10 +120,10 @@ def ref_bvh(name, tris=None):
     return nodes["box"].copy(), nodes["ints"].copy(), prims.copy()
 
 
-def ref_film(name, W, H, spp, depth, seed, nee=1, mis=1, mnee=0, threads=1):
+def ref_film(name, W, H, spp, depth, seed, nee=1, mis=1, mnee=0, threads=1, mode=1):
     with tempfile.TemporaryDirectory() as td:
         op = os.path.join(td, "film.bin")
-        out = run(["render", scene_path(name), W, H, spp, depth, seed, nee, mis, mnee, threads, op]).stdout
+        out = run(["render", scene_path(name), W, H, spp, depth, seed, nee, mis, mnee, threads, op, mode]).stdout
         raw = np.fromfile(op, dtype=np.uint8)
     secs = float([l for l in out.splitlines() if l.startswith("@@TIME@@")][-1].split()[1])
     return np.frombuffer(raw[8:].tobytes(), dtype=np.float64).reshape(H, W, 3).copy(), secs
@@ -170,6 +170,20 @@ MNEE_FILMS = [("cornell_box", 24, 14, 3, 12, 91, 1, 1), ("cornell_box", 24, 14, 
               ("kitchen_sink", 24, 14, 3, 10, 94, 1, 0)]
 
 
+# Scenes without quad / disk lights: a Whitted ray that lands on one indexes materials[negative] in the reference
+# (undefined behaviour, engine/renderer.cpp:493).  earth_demo is left out because its JPEG texture decodes differently here.
+WHITTED_FILMS = [("demo", 32, 18, 4, 50, 101), ("kitchen_points", 32, 18, 4, 12, 103), ("textured", 24, 14, 3, 10, 104), ("cornell_box", 24, 14, 3, 8, 105)]
+
+
+def make_whitted_fixtures():
+    """Seeded single-thread films in RenderMode::Whitted (Renderer::ray_color_whitted, engine/renderer.cpp:483-569)."""
+    for (n, W, H, spp, depth, seed) in WHITTED_FILMS:
+        film, _ = ref_film(n, W, H, spp, depth, seed, mode=0)
+        tag = f"{n}_{W}x{H}_s{spp}_d{depth}_seed{seed}_whitted"
+        np.savez_compressed(os.path.join(HERE, "films", tag + ".npz"), film=film, scene=n, W=W, H=H, spp=spp, depth=depth, seed=seed, nee=1, mis=1, mode=0)
+        print("film", tag, float(film.mean()))
+
+
 def make_mnee_fixtures():
     """Seeded single-thread films with use_mnee = true (the CLI default of the reference)."""
     for (n, W, H, spp, depth, seed, nee, mis) in MNEE_FILMS:
@@ -191,6 +205,9 @@ def main():
         os.makedirs(os.path.join(HERE, sub), exist_ok=True)
     if "--mnee-only" in sys.argv:
         make_mnee_fixtures()
+        return
+    if "--whitted-only" in sys.argv:
+        make_whitted_fixtures()
         return
     make_post_fixtures()
     if "--post-only" in sys.argv:
@@ -236,6 +253,7 @@ def main():
         print("film", tag, float(film.mean()))
 
     make_mnee_fixtures()
+    make_whitted_fixtures()
 
     # --- converged references + noise floor ----------------------------------------------
     for n, depth in (("cornell_box", 500), ("cornell_box_quad", 50), ("caustics_test", 16), ("environment_demo", 50), ("kitchen_sink", 24)):

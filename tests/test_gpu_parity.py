@@ -117,6 +117,41 @@ def test_f64_film_equals_oracle(name, nee, mis, pkg, oracle, tracer, load_scene)
     assert abs(got.mean() - ref.mean()) < mean_tol * (1 + ref.mean())
 
 
+@pytest.mark.parametrize("name", ["demo", "kitchen_points", "textured", "earth_demo", "kitchen_sink"])
+def test_whitted_film_equals_oracle(name, pkg, oracle, tracer, load_scene):
+    """RenderMode::Whitted (Renderer::ray_color_whitted, engine/renderer.cpp:483-569; the native mode of demo.json and
+    earth_demo.json): double precision agrees with the oracle on the same counter-based numbers (the oracle equals the
+    real reference bit for bit, test_seeded_film_bit_exact); single precision agrees with double to rounding."""
+    sd = load_scene(name)
+    W, H, spp = 48, 27, 8
+    over = dict(width=W, height=H, samples_per_pixel=spp, max_depth=min(sd.max_depth, 20), seed=53, mode=pkg.abi.MODE_WHITTED)
+    ref, ost = oracle.OracleScene(sd).render(sd.camera(W, H), sd.settings(**over), oracle.RNG_COUNTER, threads=16)
+    pt = tracer(sd)
+    pt.set_camera(sd.camera(W, H))
+    pt.set_settings(sd.settings(precision=pkg.abi.PRECISION_F64, **over))
+    got = pt.render().astype(np.float64)
+    st = pt.last_stats
+    loose = name in ("kitchen_sink", "kitchen_points", "earth_demo")   # checker floor in the plane y = 0 (see test_f64_film_equals_oracle)
+    if not loose:
+        assert st.samples == W * H * spp and st.rays_shadow == ost.rays_shadow and st.segments == ost.segments and st.rays_closest == ost.rays_closest
+    bad = (np.abs(got - ref) > 1e-5 * (1.0 + np.abs(ref))).any(axis=2)
+    assert bad.mean() < (0.03 if loose else 0.002), (bad.mean(), np.abs(got - ref).max())
+    assert abs(got.mean() - ref.mean()) < (3e-3 if loose else 1e-4) * (1 + ref.mean())
+    pt.set_settings(sd.settings(precision=pkg.abi.PRECISION_F32, **over))
+    f32 = pt.render().astype(np.float64)
+    assert pt.last_stats.pipeline_used == pkg.abi.PIPELINE_FUSED and pt.last_stats.samples == W * H * spp
+    if name in ("demo", "textured"):
+        # the other scenes have a checker texture on the plane y = 0: floor(y / scale) there is -1 or 0 on the sign of a
+        # rounding residue, which differs between precisions over the whole plane (texture.hpp:276-280)
+        bad = (np.abs(f32 - got) > 1e-3 * (1.0 + np.abs(got))).any(axis=2)
+        assert bad.mean() < 0.01, (bad.mean(), np.abs(f32 - got).max())
+        assert abs(f32.mean() - got.mean()) < 5e-3 * (1 + got.mean())
+    else:
+        assert abs(f32.mean() - got.mean()) < 0.05 * (1 + got.mean())
+    if name == "demo":
+        assert got.mean() > 0.05
+
+
 @pytest.mark.parametrize("name,mis", [("cornell_box", 1), ("cornell_box", 0), ("cornell_box_quad", 1), ("caustics_test", 1), ("kitchen_sink", 0), ("disk_room", 1)])
 def test_mnee_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
     """use_mnee = 1 (the reference's CLI default; MNEE::evaluate, engine/spectral/mnee.hpp:632-763): the render is

@@ -125,9 +125,10 @@ def test_seeded_film_bit_exact(path, oracle, load_scene):
     sd = load_scene(str(fx["scene"]))
     W, H = int(fx["W"]), int(fx["H"])
     st = sd.settings(width=W, height=H, samples_per_pixel=int(fx["spp"]), max_depth=int(fx["depth"]), seed=int(fx["seed"]),
-                     use_nee=int(fx["nee"]), use_mis=int(fx["mis"]), use_mnee=int(fx["mnee"]) if "mnee" in fx else 0)
+                     use_nee=int(fx["nee"]), use_mis=int(fx["mis"]), use_mnee=int(fx["mnee"]) if "mnee" in fx else 0,
+                     mode=int(fx["mode"]) if "mode" in fx else 1)
     film, _ = oracle.OracleScene(sd).render(sd.camera(W, H), st, oracle.RNG_MT19937, threads=1)
-    if len(sd.quad_lights) and int(fx["nee"]) and int(fx["mis"]):
+    if len(sd.quad_lights) and int(fx["nee"]) and int(fx["mis"]) and "mode" not in fx:
         # When a BSDF ray lands on a quad light the reference's look-ahead reads materials[-1]
         # (engine/renderer.cpp:803, undefined behaviour): whatever lies before its material array
         # is taken as an "emission".  In this build of it that garbage is denormal-sized and moves
