@@ -25,7 +25,18 @@ int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, cons
   }
   if (L.integ != INTEG_PATH) return -1;
   if (L.mode == MODE_FLAT && L.lds_mats)
-    hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+  {
+    // the flat instance comes in two sizes: the lean one for scenes without environment map, point and disk lights
+    // (less code, fewer live scalars)
+    if (!sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && sc.n_quads == 0)
+      hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH, 7>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else if (!sc.env.valid && sc.n_points == 0 && sc.n_disks == 0)
+      hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH, 3>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else if (sc.n_points == 0 && sc.n_disks == 0 && sc.n_quads == 0)
+      hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH, 6>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else
+      hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+  }
   else if (L.mode == MODE_TREE && L.lds_mats)
     hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
   else if (L.mode == MODE_TREE_UV && L.lds_mats)
