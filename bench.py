@@ -125,6 +125,20 @@ def main():
                     traffic = rec.get("hbm_bytes_per_launch")
             except (OSError, ValueError):
                 pass
+        # What actually limits the kernel (from the committed PMC profile of this workload, not measured live):
+        # VALU issue slots in use = wave-instructions x 4 cycles / (SIMDs x active cycles), and the share of lanes
+        # active per VALU instruction.
+        valu = None
+        prof = os.path.join(ROOT, "profiles", "r01_fused_flat", "pmc_per_launch.json")
+        if traffic is not None and os.path.exists(prof):
+            try:
+                c = json.load(open(prof))
+                cycles = c["GRBM_GUI_ACTIVE"] / 8.0            # summed over the 8 XCDs
+                valu = {"issue_busy": c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles),
+                        "lanes_active": c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0),
+                        "source": "profiles/r01_fused_flat/pmc_per_launch.json"}
+            except (OSError, ValueError, KeyError, ZeroDivisionError):
+                pass
         out = {
             "metric": "Msamples/s (Cornell box, NEE+MIS path tracing; Mrays/s alongside)",
             "value": total_samples / elapsed / 1e6,
@@ -146,7 +160,7 @@ def main():
             "segments_per_sample": seg / smp,
             "film_mean_clamped": mean_radiance,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic,
+                         "traffic": traffic, "valu": valu,
                          "kernel": "render_fused_kernel<float>" if pt.last_stats.pipeline_used == abi.PIPELINE_FUSED else "wavefront iteration kernels",
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
         }

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? (LEAN ? RTX_LEAN_MIN_W
   if constexpr ((LEAN & 1) != 0) { sc.env.valid = 0; sc.env.importance = 0; }
   if constexpr ((LEAN & 2) != 0) { sc.n_points = 0; sc.n_disks = 0; }
   if constexpr ((LEAN & 4) != 0) { sc.n_quads = 0; }
+  if constexpr ((LEAN & 8) != 0) { P.use_nee = 1; P.use_mis = 1; }
   const DMaterial<R>* mats = sc.mats;
   if constexpr (LDS_MATS) mats = stage_materials(sc);
   const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
