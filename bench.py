@@ -161,6 +161,8 @@ def main():
             "film_mean_clamped": mean_radiance,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "valu": valu,
+                         "note": "algorithmic bytes are the per-segment / per-shadow-ray / per-sample figures of a queue-based pipeline; the fused "
+                                 "kernel keeps that state in registers (see traffic), so frac can exceed 1: the kernel is VALU-issue bound (see valu)",
                          "kernel": "render_fused_kernel<float>" if pt.last_stats.pipeline_used == abi.PIPELINE_FUSED else "wavefront iteration kernels",
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
         }
