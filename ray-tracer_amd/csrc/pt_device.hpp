@@ -873,20 +873,7 @@ template <class R> RTX_DEV V3<R> background(const DScene<R>& sc, const DRenderPa
 // there is no divergent "which primitive type won" switch afterwards.  Test order and tie
 // rule are the reference's: bounded primitives in leaf order, then planes, quads, disks; a
 // later primitive with equal t wins.
-struct FlatCand {
-  float t;
-  int id;          // type << 24 | index, -1 = nothing yet
-  float a, b, c;   // sphere: centre; plane / quad / disk: outward normal
-  float w;         // sphere: 1 / radius; others: 0
-  int mat;
-};
-
 RTX_DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
-
-RTX_DEV void flat_accept(FlatCand& c, bool ok, float t, int id, float a, float b, float cc, float w, int mat) {
-  c.t = ok ? t : c.t; c.id = ok ? id : c.id;
-  c.a = ok ? a : c.a; c.b = ok ? b : c.b; c.c = ok ? cc : c.c; c.w = ok ? w : c.w; c.mat = ok ? mat : c.mat;
-}
 
 // ref: engine/sphere.hpp:71-92 — near root if it lies in range, else far root
 RTX_DEV bool flat_sphere_t(const DSphere<float>& s, const Ray<float>& r, float a, float inv_a, float t_min, float t_max, float& t) {
@@ -922,37 +909,35 @@ RTX_DEV bool flat_disk_t(const DDisk<float>& dl, const Ray<float>& r, float t_mi
   return ok && len2(d) <= dl.radius * dl.radius;
 }
 
+// Closest hit of a flat scene: every primitive is tested without branches; only the distance and the
+// position of the winner in the test order are carried along, its shading record is fetched at the end.
 RTX_DEV bool flat_closest(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_max, Hit<float>& h) {
-  FlatCand c;
-  c.t = t_max; c.id = -1; c.a = c.b = c.c = c.w = 0.f; c.mat = 0;
+  float best = t_max;
+  int k = -1, n = 0;
   const float a = len2(r.d), inv_a = rcp_(a);
   float t;
-  for (int i = 0; i < sc.n_prims; ++i) {   // all spheres in flat scenes, in reference leaf order
-    const int idx = sc.prims[i].index;
-    const DSphere<float>& s = sc.spheres[idx];
-    bool ok = flat_sphere_t(s, r, a, inv_a, t_min, c.t, t);
-    flat_accept(c, ok, t, (PRIM_SPHERE << 24) | idx, s.c[0], s.c[1], s.c[2], rcp_(s.radius), s.mat);
+  for (int i = 0; i < sc.n_prims; ++i, ++n) {   // all spheres in flat scenes, in reference leaf order
+    const bool ok = flat_sphere_t(sc.spheres[sc.prims[i].index], r, a, inv_a, t_min, best, t);
+    best = ok ? t : best; k = ok ? n : k;
   }
-  for (int i = 0; i < sc.n_planes; ++i) {
-    const DPlane<float>& pl = sc.planes[i];
-    bool ok = flat_plane_t(pl.p, pl.n, r, t_min, c.t, t);
-    flat_accept(c, ok, t, (PRIM_PLANE << 24) | i, pl.n[0], pl.n[1], pl.n[2], 0.f, pl.mat);
+  for (int i = 0; i < sc.n_planes; ++i, ++n) {
+    const bool ok = flat_plane_t(sc.planes[i].p, sc.planes[i].n, r, t_min, best, t);
+    best = ok ? t : best; k = ok ? n : k;
   }
-  for (int i = 0; i < sc.n_quads; ++i) {
-    const DQuad<float>& q = sc.quads[i];
-    bool ok = flat_quad_t(q, r, t_min, c.t, t);
-    flat_accept(c, ok, t, (PRIM_QUAD << 24) | i, q.n[0], q.n[1], q.n[2], 0.f, -i - 1);
+  for (int i = 0; i < sc.n_quads; ++i, ++n) {
+    const bool ok = flat_quad_t(sc.quads[i], r, t_min, best, t);
+    best = ok ? t : best; k = ok ? n : k;
   }
-  for (int i = 0; i < sc.n_disks; ++i) {
-    const DDisk<float>& q = sc.disks[i];
-    bool ok = flat_disk_t(q, r, t_min, c.t, t);
-    flat_accept(c, ok, t, (PRIM_DISK << 24) | i, q.n[0], q.n[1], q.n[2], 0.f, -1000 - i);
+  for (int i = 0; i < sc.n_disks; ++i, ++n) {
+    const bool ok = flat_disk_t(sc.disks[i], r, t_min, best, t);
+    best = ok ? t : best; k = ok ? n : k;
   }
-  if (c.id < 0) return false;
-  h.t = c.t; h.type = c.id >> 24; h.idx = c.id & 0xffffff; h.mat = c.mat; h.u = 0.f; h.v = 0.f;
-  h.p = at(r, c.t);
-  V3<float> abc = {c.a, c.b, c.c};
-  V3<float> on = c.w != 0.f ? (h.p - abc) * c.w : abc;
+  if (k < 0) return false;
+  const DFlatRec rec = sc.flat[k];
+  h.t = best; h.type = rec.type; h.idx = rec.idx; h.mat = rec.mat; h.u = 0.f; h.v = 0.f;
+  h.p = at(r, best);
+  V3<float> abc = {rec.a, rec.b, rec.c};
+  V3<float> on = rec.w != 0.f ? (h.p - abc) * rec.w : abc;
   face_normal(h, r, on);
   return true;
 }

@@ -250,6 +250,18 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
     }
     sc.wide = push(pool, wide, ok); sc.n_wide = (int32_t)wide.size();
   }
+  if (std::is_same<R, float>::value && d.n_triangles == 0 && d.n_boxes == 0 && d.n_spheres <= (size_t)kFlatMaxSpheres) {
+    std::vector<DFlatRec> recs;
+    auto rec = [&](float a, float b, float c, float w, int mat, int type, int idx) { recs.push_back(DFlatRec{a, b, c, w, mat, type, idx, 0}); };
+    for (const DPrimRef& p : bvh.prims) {   // all spheres here, in the reference's leaf order
+      const rtx_sphere& s = d.spheres[p.index];
+      rec((float)s.center[0], (float)s.center[1], (float)s.center[2], 1.0f / (float)s.radius, s.material_id, PRIM_SPHERE, p.index);
+    }
+    for (size_t i = 0; i < d.n_planes; ++i) rec((float)d.planes[i].normal[0], (float)d.planes[i].normal[1], (float)d.planes[i].normal[2], 0.f, d.planes[i].material_id, PRIM_PLANE, (int)i);
+    for (size_t i = 0; i < d.n_quad_lights; ++i) rec((float)d.quad_lights[i].normal[0], (float)d.quad_lights[i].normal[1], (float)d.quad_lights[i].normal[2], 0.f, -(int)i - 1, PRIM_QUAD, (int)i);
+    for (size_t i = 0; i < d.n_disk_lights; ++i) rec((float)d.disk_lights[i].normal[0], (float)d.disk_lights[i].normal[1], (float)d.disk_lights[i].normal[2], 0.f, -1000 - (int)i, PRIM_DISK, (int)i);
+    sc.flat = push(pool, recs, ok);
+  }
   sc.spheres = push(pool, sph, ok); sc.planes = push(pool, pls, ok); sc.tris = push(pool, tris, ok); sc.boxes = push(pool, boxes, ok);
   sc.points = push(pool, pts, ok); sc.quads = push(pool, quads, ok); sc.disks = push(pool, disks, ok); sc.mats = push(pool, mats, ok);
   sc.nodes = push(pool, nodes, ok);

@@ -45,6 +45,11 @@ struct alignas(16) DNodeWide { float lo_x[4], lo_y[4], lo_z[4], hi_x[4], hi_y[4]
 constexpr int32_t kWideEmpty = 0x7ffffffe;
 // Levels of a four-wide walk's stack kept in LDS; deeper levels (rare) spill to global memory.
 constexpr int kWalkLdsLevels = 12;
+// Shading record of one primitive of a flat scene, in the order the flat intersection tests them (spheres in the
+// reference's leaf order, planes, quad lights, disk lights): what the winner's normal and material need, fetched
+// once per hit instead of being carried through every test.  sphere: (a,b,c) = centre, w = 1 / radius; others:
+// (a,b,c) = outward normal, w = 0.
+struct alignas(16) DFlatRec { float a, b, c, w; int32_t mat, type, idx, pad; };
 // Leaf-ordered primitive records (48 bytes, three 16-byte fetches): a triangle's vertices in
 // place, or (type != PRIM_TRIANGLE) a reference to a sphere / box tested through its own table.
 struct alignas(16) DLeafPrim { float v0[3]; int32_t mat; float v1[3]; int32_t index; float v2[3]; int32_t type; };
@@ -65,6 +70,7 @@ template <class R> struct DScene {
   const DNode2<R>* nodes; const DPrimRef* prims;    // production BVH + primitive order (reference leaf order)
   const DNodePair* pairs; const DLeafPrim* leaf_prims; // single-precision traversal layout (NULL in the double scene)
   const DNodeWide* wide;
+  const DFlatRec* flat;                                // flat scenes only (single precision)
   int32_t n_spheres, n_planes, n_tris, n_boxes, n_points, n_quads, n_disks, n_mats, n_images, n_emissive;
   int32_t n_nodes, n_prims, n_pairs, n_wide;
   DEnv<R> env;
