@@ -104,6 +104,10 @@ enum { RTX_PIPELINE_AUTO = 0, RTX_PIPELINE_FUSED = 1, RTX_PIPELINE_WAVEFRONT = 2
  * Whitted = Renderer::ray_color_whitted (engine/renderer.cpp:483-569), PathTrace = ray_color_path (:580-841).
  * Any other value returns RTX_ERR_UNSUPPORTED. */
 enum { RTX_MODE_WHITTED = 0, RTX_MODE_PATHTRACE = 1 };
+/* Counter-based generator behind the samples (the reference's per-thread mt19937 has no parallel counterpart):
+ * AUTO = PCG4D for single precision, PHILOX for double; PHILOX = Philox-4x32-10 (Random123), the generator the
+ * double-precision parity mode and the CPU oracle share; PCG4D = the pcg4d hash, a third of the multiplies. */
+enum { RTX_RNG_AUTO = 0, RTX_RNG_PHILOX = 1, RTX_RNG_PCG4D = 2 };
 
 /* Renderer::Settings (engine/renderer.hpp:101-133), PathTrace mode members, plus what a
  * GPU backend needs in addition (seed, precision, pipeline, row sharding). */
@@ -121,7 +125,7 @@ typedef struct rtx_settings {
    * shard_count = 1 renders the whole film. */
   int32_t shard_index, shard_count;
   int32_t mode;                             /* RTX_MODE_* (Renderer::Settings::mode); Whitted runs in the fused pipeline */
-  int32_t reserved_;
+  int32_t rng;                              /* RTX_RNG_* */
 } rtx_settings;
 
 typedef struct rtx_stats {

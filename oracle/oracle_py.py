@@ -16,7 +16,7 @@ abi = _pkg.abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_HERE, "libpt_oracle.so")
-RNG_MT19937, RNG_COUNTER = 0, 1
+RNG_MT19937, RNG_COUNTER, RNG_COUNTER_PCG = 0, 1, 2
 _lib = None
 
 
@@ -115,6 +115,15 @@ def postprocess(film, tone_mapper, exposure):
     rc = L.orc_postprocess(f.ctypes.data, W, H, int(tone_mapper), float(exposure), out.ctypes.data)
     assert rc == 0
     return out
+
+
+def pcg4d(pixel, sample, block, seed):
+    o = np.zeros(4, dtype=np.uint32)
+    L = lib()
+    L.orc_pcg4d.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.orc_pcg4d.restype = None
+    L.orc_pcg4d(int(pixel), int(sample), int(block), int(seed), o.ctypes.data)
+    return o
 
 
 def philox(ctr, key):

@@ -571,7 +571,22 @@ struct MtSampler {
 // 0 and 1, times 2^-24).  Path vertex b draws one block, 1+b, cut into 16-bit fields:
 // word0 = light u | light v, word1 = scatter u1 | scatter u2, word2 = light select | roulette,
 // word3 = fresnel | spare; a field k maps to (k + 0.5) / 65536.
+inline void pcg4d(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t out[4]) {   // the GPU's pcg4d (pt_device.hpp), word for word
+  x = x * 1664525u + 1013904223u; y = y * 1664525u + 1013904223u; z = z * 1664525u + 1013904223u; w = w * 1664525u + 1013904223u;
+  for (int i = 0; i < 3; ++i) {
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+  }
+  out[0] = x; out[1] = y; out[2] = z; out[3] = w;
+}
+
 struct CounterSampler {
+  bool pcg = false;   // fill blocks with pcg4d(pixel, sample, block, seed) instead of Philox
+  void block(uint32_t blk, uint32_t o[4]) {
+    if (pcg) { pcg4d(key[0], sample, blk, key[1], o); return; }
+    uint32_t c[4] = {sample, blk, 0, 0};
+    philox4x32_10(c, key, o);
+  }
   uint32_t key[2]{0, 0}, sample = 0;
   uint32_t w[4];
   int bounce = -1;
@@ -581,7 +596,7 @@ struct CounterSampler {
   void begin_sample(uint32_t pixel, uint32_t seed, uint32_t s) { key[0] = pixel; key[1] = seed; sample = s; bounce = -1; have = false; }
   void begin_bounce(int bn) { bounce = bn; have = false; }
   uint32_t* W() {
-    if (!have) { uint32_t c[4] = {sample, bounce < 0 ? 0u : 1u + (uint32_t)bounce, 0, 0}; philox4x32_10(c, key, w); have = true; }
+    if (!have) { block(bounce < 0 ? 0u : 1u + (uint32_t)bounce, w); have = true; }
     return w;
   }
   double jitter_x() { return u24(W()[0]); }
@@ -593,8 +608,8 @@ struct CounterSampler {
   double fresnel() { return hi(W()[3]); }
   // MNEE light j of this vertex: extra block (1 + bounce) | ((1 + j / 4) << 16), word j % 4, high | low field
   void mnee_pair(int j, double& a, double& b) {
-    uint32_t c[4] = {sample, (1u + (uint32_t)bounce) | ((1u + (uint32_t)j / 4u) << 16), 0, 0}, o[4];
-    philox4x32_10(c, key, o);
+    uint32_t o[4];
+    block((1u + (uint32_t)bounce) | ((1u + (uint32_t)j / 4u) << 16), o);
     a = hi(o[j & 3]); b = lo(o[j & 3]);
   }
   V3 unit_vector() {  // uniform on the sphere: same law as the normalised rejection sample
@@ -1331,6 +1346,7 @@ int orc_render(const orc_scene* s, const rtx_camera* cam, const rtx_settings* st
 #pragma omp parallel num_threads(threads) reduction(+ : closest, shadow, segments, rows_done)
     {
       CounterSampler rng;
+      rng.pcg = rng_mode == ORC_RNG_COUNTER_PCG;
       Tally tl;
 #pragma omp for schedule(dynamic, 1)
       for (int y = 0; y < H; ++y) {
@@ -1409,6 +1425,8 @@ double pp_tone(double x, int mapper) {                                          
   }
 }
 }  // namespace
+
+extern "C" void orc_pcg4d(uint32_t pixel, uint32_t sample, uint32_t block, uint32_t seed, uint32_t out[4]) { pcg4d(pixel, sample, block, seed, out); }
 
 extern "C" int orc_postprocess(const float* film, int width, int height, int tone_mapper, double exposure, uint8_t* rgb8) {
   if (!film || !rgb8 || width <= 0 || height <= 0) return RTX_ERR_INVALID_ARGUMENT;

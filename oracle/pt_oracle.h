@@ -18,7 +18,8 @@ extern "C" {
 typedef struct orc_scene orc_scene;
 
 enum { ORC_RNG_MT19937 = 0,  /* std::mt19937 drawn in the reference's order (engine/renderer.cpp:33-56) */
-       ORC_RNG_COUNTER = 1   /* Philox-4x32-10 keyed by (pixel, seed): one block per path vertex, the generator the GPU uses */ };
+       ORC_RNG_COUNTER = 1,  /* Philox-4x32-10 keyed by (pixel, seed): one block per path vertex, the GPU's RTX_RNG_PHILOX */
+       ORC_RNG_COUNTER_PCG = 2 /* the same block layout filled by the pcg4d hash, the GPU's RTX_RNG_PCG4D */ };
 
 int  orc_create(const rtx_scene_desc* desc, orc_scene** out);
 void orc_destroy(orc_scene* s);
@@ -46,6 +47,9 @@ int orc_kat(const orc_scene* s, unsigned seed, int n, double* out, size_t cap, s
  * sqrt gamma, int(255.999 * v), vertical flip.  `film`: width*height*3 floats, row 0 = bottom;
  * `rgb8`: width*height*3 bytes, row 0 = TOP. */
 int orc_postprocess(const float* film, int width, int height, int tone_mapper, double exposure, uint8_t* rgb8);
+
+/* One block of the pcg4d generator for (pixel, sample, block, seed), exposed for statistical tests. */
+void orc_pcg4d(uint32_t pixel, uint32_t sample, uint32_t block, uint32_t seed, uint32_t out[4]);
 
 /* The counter-based generator, exposed so tests can pin it (Random123 known answers). */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -28,8 +28,8 @@ int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, cons
   {
     // the flat instance comes in two sizes: the lean one for scenes without environment map, point and disk lights
     // (less code, fewer live scalars)
-    if (!sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && sc.n_quads == 0 && P.use_nee && P.use_mis)
-      hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH, 15>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    if (!sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && sc.n_quads == 0 && P.use_nee && P.use_mis && P.rng == 1 /* RNG_PCG4D */)
+      hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH, 31>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     else if (!sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && sc.n_quads == 0)
       hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH, 7>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     else if (!sc.env.valid && sc.n_points == 0 && sc.n_disks == 0)

@@ -590,6 +590,31 @@ RTX_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1) {
   }
   return {c0, c1, c2, c3};
 }
+// A second, cheaper block generator for the single-precision production path: the pcg4d hash (Jarzynski & Olano,
+// "Hash Functions for GPU Rendering", 2020) of (pixel, sample, block, seed), run for three mix rounds with an xor-shift
+// after each (both halves of every word are used).  16 low multiplies instead of Philox's 20 low + 20 high ones; on the
+// VALU-bound Cornell kernel the generator was ~15 % of the time.  The published two rounds are not enough here: over 64
+// seeds the image error (relMSE against the reference's converged films) had twice Philox's spread and outliers; with
+// three rounds mean and spread equal Philox's on all three test scenes (scripts/rng_quality.py).
+#ifndef RTX_PCG_ROUNDS
+#define RTX_PCG_ROUNDS 3
+#endif
+RTX_DEV U4 pcg4d(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+  x = x * 1664525u + 1013904223u; y = y * 1664525u + 1013904223u; z = z * 1664525u + 1013904223u; w = w * 1664525u + 1013904223u;
+#pragma unroll
+  for (int i = 0; i < RTX_PCG_ROUNDS; ++i) {
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+  }
+  return {x, y, z, w};
+}
+enum { RNG_PHILOX = 0, RNG_PCG4D = 1 };
+struct PathKey;
+RTX_DEV U4 rng_block(uint32_t rng, uint32_t pixel, uint32_t seed, uint32_t sample, uint32_t block) {
+  if (rng == RNG_PCG4D) return pcg4d(pixel, sample, block, seed);
+  return philox4x32_10(sample, block, pixel, seed);
+}
+
 template <class R> RTX_DEV R u24(uint32_t x) { return R(x >> 8) * R(1.0 / 16777216.0); }
 template <class R> RTX_DEV R u16hi(uint32_t x) { return (R(x >> 16) + R(0.5)) * R(1.0 / 65536.0); }
 template <class R> RTX_DEV R u16lo(uint32_t x) { return (R(x & 0xffffu) + R(0.5)) * R(1.0 / 65536.0); }
@@ -982,10 +1007,10 @@ template <class R> struct PathState {
   uint32_t bounce_flags;   // bounce << 4 | F_*
 };
 
-struct PathKey { uint32_t pixel, seed, sample; };
+struct PathKey { uint32_t pixel, seed, sample, rng; };   // rng: RNG_PHILOX or RNG_PCG4D
 
 template <class R> RTX_DEV void path_begin(PathState<R>& ps, const DCamera<R>& cam, const DRenderParams& P, int x, int y, PathKey key) {
-  U4 j = philox4x32_10(key.sample, 0u, key.pixel, key.seed);
+  U4 j = rng_block(key.rng, key.pixel, key.seed, key.sample, 0u);
   R u = (R(x) + u24<R>(j.x)) / R(P.width);     // ref: engine/renderer.cpp:385-386
   R v = (R(y) + u24<R>(j.y)) / R(P.height);
   V3<R> o = mk3(cam.origin);                    // ref: engine/scene.hpp:99-108
@@ -1076,7 +1101,7 @@ RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, const Hit<R>
   V3<R> atten = surf;
   uint32_t flags = F_ALIVE;
   R bsdf_pdf = R(0);
-  const U4 rn = philox4x32_10(key.sample, 1u + (uint32_t)bounce, key.pixel, key.seed);
+  const U4 rn = rng_block(key.rng, key.pixel, key.seed, key.sample, 1u + (uint32_t)bounce);
 
   if (m.type == MAT_LAMBERTIAN) {
     if (nee) {  // ref: engine/renderer.cpp:654-714
@@ -1192,7 +1217,7 @@ RTX_DEV uint32_t whitted_vertex(PathState<R>& ps, const bool hit, const Hit<R>& 
   }
   const DMaterial<R>& m = mats[rec.mat];
   const V3<R> surf = albedo_at(sc, m, rec);
-  const U4 rn = philox4x32_10(key.sample, 1u + (uint32_t)bounce, key.pixel, key.seed);
+  const U4 rn = rng_block(key.rng, key.pixel, key.seed, key.sample, 1u + (uint32_t)bounce);
   V3<R> dir;
   if (m.type == MAT_LAMBERTIAN) {
     V3<R> direct = {R(0), R(0), R(0)};

@@ -56,7 +56,8 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #define RTX_LEAN_MIN_WAVES 6
 #endif
 // LEAN (bit mask) compiles scene features out of an instance by pinning the scene's counts to zero, so that every
-// branch on them folds away: 1 = no environment map, 2 = no point and no disk lights, 4 = no quad lights.
+// branch on them folds away: 1 = no environment map, 2 = no point and no disk lights, 4 = no quad lights,
+// 8 = NEE and MIS on, 16 = the pcg4d generator.
 template <class R, int MODE, bool LDS_MATS, int INTEG = INTEG_PATH, int LEAN = 0>
 __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? (LEAN ? RTX_LEAN_MIN_WAVES : RTX_FLAT_MIN_WAVES) : 1)) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
                                                                DCounters* __restrict__ counters, int stack_first_int) {
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? (LEAN ? RTX_LEAN_MIN_W
   if constexpr ((LEAN & 2) != 0) { sc.n_points = 0; sc.n_disks = 0; }
   if constexpr ((LEAN & 4) != 0) { sc.n_quads = 0; }
   if constexpr ((LEAN & 8) != 0) { P.use_nee = 1; P.use_mis = 1; }
+  if constexpr ((LEAN & 16) != 0) { P.rng = RNG_PCG4D; }
   const DMaterial<R>* mats = sc.mats;
   if constexpr (LDS_MATS) mats = stage_materials(sc);
   const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? (LEAN ? RTX_LEAN_MIN_W
   V3<R> sum = {R(0), R(0), R(0)};
   uint32_t cur = 0, xy = 0;
   int s = 0, s_end = 0;
-  PathKey key = {0u, P.seed, 0u};
+  PathKey key = {0u, P.seed, 0u, (uint32_t)P.rng};
 
   auto fetch = [&]() -> bool {
     if (next >= n_items) return false;

@@ -195,7 +195,7 @@ template <class R, class Trace> RTX_DEV bool mnee_connect(const DScene<R>& sc, c
 // The two uniforms of the j-th light of a vertex: extra Philox block (1 + bounce) | ((1 + j / 4) << 16),
 // word j % 4, high | low 16-bit field.
 template <class R> RTX_DEV void mnee_pair(PathKey key, int bounce, int j, R& a, R& b) {
-  const U4 o = philox4x32_10(key.sample, (1u + (uint32_t)bounce) | ((1u + (uint32_t)j / 4u) << 16), key.pixel, key.seed);
+  const U4 o = rng_block(key.rng, key.pixel, key.seed, key.sample, (1u + (uint32_t)bounce) | ((1u + (uint32_t)j / 4u) << 16));
   const uint32_t w = (j & 3) == 0 ? o.x : (j & 3) == 1 ? o.y : (j & 3) == 2 ? o.z : o.w;
   a = u16hi<R>(w); b = u16lo<R>(w);
 }

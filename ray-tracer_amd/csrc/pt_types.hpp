@@ -88,6 +88,7 @@ struct DRenderParams {
   int32_t shard_index, shard_count, rows;  // rows = rows owned by this shard
   int32_t n_chunks, chunk_spp;             // samples are summed in fixed chunks (deterministic film)
   uint32_t seed;
+  int32_t rng;                              // RNG_PHILOX / RNG_PCG4D (pt_device.hpp)
   double bg[3], bg_top[3], bg_bottom[3];
 };
 

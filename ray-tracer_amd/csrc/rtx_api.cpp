@@ -157,6 +157,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   if (s->precision != RTX_PRECISION_F32 && s->precision != RTX_PRECISION_F64) return fail(RTX_ERR_INVALID_ARGUMENT, "precision %d", s->precision);
   if (s->pipeline < RTX_PIPELINE_AUTO || s->pipeline > RTX_PIPELINE_WAVEFRONT) return fail(RTX_ERR_INVALID_ARGUMENT, "pipeline %d", s->pipeline);
   if (s->mode != RTX_MODE_WHITTED && s->mode != RTX_MODE_PATHTRACE) return fail(RTX_ERR_UNSUPPORTED, "render mode %d: only Whitted (0) and PathTrace (1) are implemented", s->mode);
+  if (s->rng < RTX_RNG_AUTO || s->rng > RTX_RNG_PCG4D) return fail(RTX_ERR_INVALID_ARGUMENT, "rng %d", s->rng);
   if (!host_out && !dev_out) return fail(RTX_ERR_INVALID_ARGUMENT, "output buffer is NULL");
   HIP_TRY(hipSetDevice(c->device));
   auto wall0 = std::chrono::steady_clock::now();
@@ -174,6 +175,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   P.chunk_spp = (P.spp + target_chunks - 1) / target_chunks;
   P.n_chunks = (P.spp + P.chunk_spp - 1) / P.chunk_spp;
   P.seed = s->seed;
+  P.rng = (s->rng == RTX_RNG_PCG4D || (s->rng == RTX_RNG_AUTO && s->precision == RTX_PRECISION_F32 && !(s->use_mnee && s->use_nee && s->mode == RTX_MODE_PATHTRACE))) ? 1 /* RNG_PCG4D */ : 0;
   for (int i = 0; i < 3; ++i) { P.bg[i] = s->background_color[i]; P.bg_top[i] = s->background_top[i]; P.bg_bottom[i] = s->background_bottom[i]; }
 
   const unsigned long long npix = (unsigned long long)P.rows * P.width;

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DCamera<float> cam, DRende
     }
     if (live) {
       PathState<float> ps;
-      PathKey key = {pixel, P.seed, s};
+      PathKey key = {pixel, P.seed, s, (uint32_t)P.rng};
       path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key);
       A.sample[sl] = s + 1u;     // index of the NEXT sample; the current one is sample - 1
       A.sum[0][sl] = sum.x; A.sum[1][sl] = sum.y; A.sum[2][sl] = sum.z;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene<float> sc, DRenderPara
   ps.acc = {A.acc[0][slot], A.acc[1][slot], A.acc[2][slot]};
   ps.bsdf_pdf = A.bsdf_pdf[slot];
   ps.bounce_flags = A.bflags[slot];
-  PathKey key = {A.pixel[slot], P.seed, A.sample[slot] - 1u};
+  PathKey key = {A.pixel[slot], P.seed, A.sample[slot] - 1u, (uint32_t)P.rng};
   Hit<float> rec;
   const bool hit = wf_load_hit<MODE>(sc, A, slot, ps.ray, rec);
   did = path_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<float>& sr, float t_max, V3<float> contrib) {

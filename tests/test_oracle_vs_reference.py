@@ -223,3 +223,29 @@ def test_postprocess_numpy_mirror_and_ppm_writer(pkg, tmp_path):
     assert tok[:4] == ["P3", str(W), str(H), "255"]
     assert np.array_equal(np.array(tok[4:], dtype=np.int64).reshape(H, W, 3), fx["m3_e0"])
     assert path.read_text().count("\n") == 3 + W * H
+
+
+def test_pcg4d_block_generator_statistics(oracle):
+    """The production generator of the single-precision path (pcg4d hash of (pixel, sample, block, seed) + xor-shift).
+    Every 16-bit field and both 24-bit jitter fields must be uniform (chi-square over 256 bins), fields of one block and
+    the same field of neighbouring pixels / samples / blocks uncorrelated, and it must differ from Philox."""
+    n = 4096
+    rows = []
+    for pixel in range(n):
+        rows.append(oracle.pcg4d(pixel, 3, 1, 1234))
+    by_pixel = np.array(rows, dtype=np.uint64)
+    by_sample = np.array([oracle.pcg4d(777, s, 2, 1234) for s in range(n)], dtype=np.uint64)
+    by_block = np.array([oracle.pcg4d(4242, 5, b, 1234) for b in range(n)], dtype=np.uint64)
+    for words in (by_pixel, by_sample, by_block):
+        fields = np.concatenate([(words >> 16) & 0xffff, words & 0xffff], axis=1).astype(np.float64) / 65536.0   # 8 fields
+        for k in range(8):
+            hist, _ = np.histogram(fields[:, k], bins=256, range=(0.0, 1.0))
+            chi2 = ((hist - n / 256.0) ** 2 / (n / 256.0)).sum()
+            assert 150.0 < chi2 < 380.0, (k, chi2)            # 255 degrees of freedom: mean 255, sd 22.6
+            assert abs(np.corrcoef(fields[:-1, k], fields[1:, k])[0, 1]) < 0.06, k     # neighbours in the sweep
+        c = np.corrcoef(fields.T)
+        assert np.abs(c - np.eye(8)).max() < 0.07
+        j = (words[:, :2] >> 8).astype(np.float64) / 16777216.0
+        assert abs(j.mean() - 0.5) < 0.02 and abs(np.corrcoef(j.T)[0, 1]) < 0.06
+    assert not np.array_equal(oracle.pcg4d(1, 2, 3, 4), oracle.philox([2, 3, 0, 0], [1, 4]))
+    assert [int(v) for v in oracle.pcg4d(0, 0, 0, 0)] == [int(v) for v in oracle.pcg4d(0, 0, 0, 0)]
