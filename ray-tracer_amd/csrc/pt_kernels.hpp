@@ -52,6 +52,9 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #endif
 // The lean flat instances (see LEAN below) need fewer registers: measured best at 6 waves per SIMD
 // (3: 310.8 ms, 4: 309.7, 5: 298.9, 6: 292.3, 7: 296.1, 8: 330.4 on the 1080p Cornell box).
+#ifndef RTX_LEAN_ENV_MIN_WAVES
+#define RTX_LEAN_ENV_MIN_WAVES 6   // lean instance that keeps the environment map
+#endif
 #ifndef RTX_LEAN_MIN_WAVES
 #define RTX_LEAN_MIN_WAVES 6
 #endif
@@ -59,7 +62,7 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 // branch on them folds away: 1 = no environment map, 2 = no point and no disk lights, 4 = no quad lights,
 // 8 = NEE and MIS on, 16 = the pcg4d generator.
 template <class R, int MODE, bool LDS_MATS, int INTEG = INTEG_PATH, int LEAN = 0>
-__global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? (LEAN ? RTX_LEAN_MIN_WAVES : RTX_FLAT_MIN_WAVES) : 1)) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
+__global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? ((LEAN & 1) ? RTX_LEAN_MIN_WAVES : (LEAN ? RTX_LEAN_ENV_MIN_WAVES : RTX_FLAT_MIN_WAVES)) : 1)) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
                                                                DCounters* __restrict__ counters, int stack_first_int) {
   if constexpr ((LEAN & 1) != 0) { sc.env.valid = 0; sc.env.importance = 0; }
   if constexpr ((LEAN & 2) != 0) { sc.n_points = 0; sc.n_disks = 0; }
