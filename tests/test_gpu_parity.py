@@ -275,7 +275,7 @@ def test_render_device_buffer_matches_host_buffer(pkg, tracer, load_scene):
 
 
 def test_full_size_properties(pkg, tracer, load_scene):
-    """BASELINE's headline configuration (Cornell box, 1920x1080, NEE+MIS, depth 500) at reduced
+    """The headline configuration (Cornell box, 1920x1080, NEE+MIS, depth 500) at reduced
     spp: sample count, film mean against the reference's converged low-resolution film, and
     agreement between two shards and the full film on their rows."""
     fx = np.load(os.path.join(GOLDEN, "converged", "cornell_box.npz"))
