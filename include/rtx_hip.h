@@ -74,6 +74,11 @@ typedef struct rtx_material {
   double tex_color1[3];
   double tex_color2[3];
   double tex_scale;
+  /* NormalMap (engine/texture.hpp:45-49; Material::normal_map / has_normal_map, engine/material.hpp:58-60), applied by
+   * apply_normal_map (engine/renderer.cpp:72-94) in both render modes.  A zero-initialised record has none. */
+  int32_t has_normal_map;  /* Material::has_normal_map */
+  int32_t normal_image;    /* index into rtx_scene_desc::images of the tangent-space map; read when has_normal_map */
+  double normal_strength;  /* NormalMap::strength */
 } rtx_material;
 
 /* Texture image data (engine/texture.hpp:196-199): 8-bit RGB, row 0 = top */

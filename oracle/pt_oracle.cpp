@@ -51,6 +51,7 @@ inline V3 at(const Ray& r, double t) { return add(r.o, scale(r.d, t)); }  // cor
 // identity of the primitive that produced it.
 struct Hit {
   V3 p{0, 0, 0}, n{0, 0, 0};
+  V3 tangent{0, 0, 0};   // hit_record::tangent: every hit routine writes it
   double t = 0, u = 0, v = 0;
   bool front = false;
   int mat = 0;
@@ -218,6 +219,8 @@ bool hit_sphere(const rtx_sphere& s, const Ray& r, double t_min, double t_max, H
   double phi = std::atan2(-on.z, on.x) + kPi;
   h.u = phi / (2.0 * kPi);
   h.v = theta / kPi;
+  if (std::fabs(on.y) > 0.999) h.tangent = {1.0, 0.0, 0.0};   // get_sphere_tangent, sphere.hpp:39-50
+  else h.tangent = normalize(V3{-on.z, 0.0, on.x});
   return true;
 }
 
@@ -230,6 +233,8 @@ bool hit_plane(const rtx_plane& pl, const Ray& r, double t_min, double t_max, Hi
   h.t = t; h.p = at(r, t);
   face_normal(h, r, n);
   h.mat = pl.material_id;
+  V3 up = (std::fabs(n.y) < 0.999) ? V3{0, 1, 0} : V3{1, 0, 0};   // primitives.hpp:55-57
+  h.tangent = normalize(cross(up, n));
   return true;  // u, v deliberately left as they were (the reference does not write them)
 }
 
@@ -252,6 +257,7 @@ bool hit_triangle(const rtx_triangle& tr, const Ray& r, double t_min, double t_m
   face_normal(h, r, normalize(cross(e1, e2)));
   h.mat = tr.material_id;
   h.u = u; h.v = v;
+  h.tangent = normalize(e1);   // primitives.hpp:119
   return true;
 }
 
@@ -276,6 +282,8 @@ bool hit_box(const rtx_box& b, const Ray& r, double t_min, double t_max, Hit& h)
   else on = {0, 0, 1};
   face_normal(h, r, on);
   h.mat = b.material_id;
+  if (std::fabs(on.x) > 0.5) h.tangent = {0, 0, 1};   // primitives.hpp:197-204
+  else h.tangent = {1, 0, 0};
   return true;
 }
 
@@ -294,6 +302,7 @@ bool hit_quad(const rtx_quad_light& q, const Ray& r, double t_min, double t_max,
   h.t = t; h.p = p;
   face_normal(h, r, n);
   h.u = up; h.v = vp;
+  h.tangent = normalize(eu);   // primitives.hpp:310
   return true;
 }
 
@@ -313,6 +322,7 @@ bool hit_disk(const rtx_disk_light& dl, const Ray& r, double t_min, double t_max
   double dist = std::sqrt(d2);
   h.u = (dist > 1e-8) ? (dot(d, mk(dl.tangent)) / dist + 1.0) * 0.5 : 0.5;
   h.v = (dist > 1e-8) ? (dot(d, mk(dl.bitangent)) / dist + 1.0) * 0.5 : 0.5;
+  h.tangent = mk(dl.tangent);   // primitives.hpp:425
   return true;
 }
 
@@ -508,6 +518,30 @@ V3 albedo_at(const orc_scene& s, const rtx_material& m, V3 p, double u, double v
     }
   }
   return mk(m.tex_color1);
+}
+
+// NormalMap::sample (texture.hpp:83-109) followed by apply_normal_map (renderer.cpp:72-94).
+void apply_normal_map(const orc_scene& s, const rtx_material& m, Hit& rec) {
+  if (!m.has_normal_map) return;
+  V3 tn{0.0, 0.0, 1.0};
+  if (m.normal_image >= 0 && m.normal_image < (int)s.img_data.size() && s.img_w[m.normal_image] > 0 && s.img_h[m.normal_image] > 0) {
+    int w = s.img_w[m.normal_image], h = s.img_h[m.normal_image];
+    double u = std::clamp(rec.u, 0.0, 1.0);
+    double v = 1.0 - std::clamp(rec.v, 0.0, 1.0);
+    int i = std::min((int)(u * w), w - 1), j = std::min((int)(v * h), h - 1);
+    const uint8_t* t = &s.img_data[m.normal_image][((size_t)j * w + i) * 3];
+    double nx = (t[0] / 255.0) * 2.0 - 1.0, ny = (t[1] / 255.0) * 2.0 - 1.0, nz = (t[2] / 255.0) * 2.0 - 1.0;
+    if (m.normal_strength < 1.0) {
+      nx = nx * m.normal_strength;
+      ny = ny * m.normal_strength;
+      nz = nz * m.normal_strength + (1.0 - m.normal_strength);
+    }
+    tn = normalize(V3{nx, ny, nz});
+  }
+  V3 N = rec.n, T = rec.tangent;
+  T = normalize(sub(T, scale(N, dot(N, T))));
+  V3 B = cross(N, T);
+  rec.n = normalize(V3{T.x * tn.x + B.x * tn.y + N.x * tn.z, T.y * tn.x + B.y * tn.y + N.y * tn.z, T.z * tn.x + B.z * tn.y + N.z * tn.z});
 }
 
 inline double schlick(double cosine, double ref_idx) {
@@ -1052,6 +1086,7 @@ V3 path_radiance(const orc_scene& s, const rtx_settings& st, Ray r, S& rng, Tall
       break;
     }
     const rtx_material& m = s.mats[rec.mat];
+    apply_normal_map(s, m, rec);   // renderer.cpp:635
     V3 surf = albedo_at(s, m, rec.p, rec.u, rec.v);
     if (bounce == 0 || spec || !nee) acc = add(acc, mul(thr, mk(m.emission)));
     V3 sdir{0, 0, 0};
@@ -1173,6 +1208,7 @@ V3 whitted_radiance(const orc_scene& s, const rtx_settings& st, Ray r, int depth
     tl.segments++;
     if (rec.mat >= 0) {   // a quad / disk light hit indexes materials[negative] in the reference (undefined); defined as a miss
       const rtx_material& m = s.mats[rec.mat];
+      apply_normal_map(s, m, rec);   // renderer.cpp:496
       V3 surf = albedo_at(s, m, rec.p, rec.u, rec.v);
       switch (m.type) {
         case RTX_MAT_LAMBERTIAN: {

@@ -116,7 +116,8 @@ int cmd_dump(const char* path) {
     printf(",\"fuzz\":"); jnum(m.fuzz); printf(",\"ior\":"); jnum(m.refraction_index);
     printf(",\"has_texture\":%d,\"tex_type\":%d,\"tex_c1\":", (int)m.has_texture, (int)m.texture.type); jvec(m.texture.color1);
     printf(",\"tex_c2\":"); jvec(m.texture.color2); printf(",\"tex_scale\":"); jnum(m.texture.scale);
-    printf(",\"tex_w\":%d,\"tex_h\":%d,\"has_normal_map\":%d}", m.texture.image_width, m.texture.image_height, (int)m.has_normal_map);
+    printf(",\"tex_w\":%d,\"tex_h\":%d,\"has_normal_map\":%d", m.texture.image_width, m.texture.image_height, (int)m.has_normal_map);
+    printf(",\"nmap_w\":%d,\"nmap_h\":%d,\"nmap_strength\":", m.normal_map.width, m.normal_map.height); jnum(m.normal_map.strength); printf("}");
   }
   printf("],\"spheres\":[");
   for (size_t i = 0; i < s.spheres.size(); ++i) {
@@ -345,6 +346,15 @@ int cmd_kat(const char* scene_path, unsigned seed, int n, const char* out) {
 int cmd_texels(const char* scene_path, const char* prefix) {
   auto d = SceneLoader::load(scene_path);
   for (size_t i = 0; i < d.scene.materials.size(); ++i) {
+    const NormalMap& nm = d.scene.materials[i].normal_map;
+    if (d.scene.materials[i].has_normal_map && nm.valid()) {   // <prefix>n<material id>.rgb
+      std::string fn = std::string(prefix) + "n" + std::to_string(i) + ".rgb";
+      FILE* f = fopen(fn.c_str(), "wb");
+      int32_t hdr[2] = {nm.width, nm.height};
+      fwrite(hdr, 4, 2, f);
+      fwrite(nm.data->data(), 1, nm.data->size(), f);
+      fclose(f);
+    }
     const Texture& t = d.scene.materials[i].texture;
     if (!d.scene.materials[i].has_texture || !t.image_data) continue;
     std::string fn = std::string(prefix) + std::to_string(i) + ".rgb";

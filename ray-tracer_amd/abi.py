@@ -46,7 +46,8 @@ class DiskLight(C.Structure):
 class Material(C.Structure):
     _fields_ = [("type", C.c_int32), ("has_texture", C.c_int32), ("albedo", d3), ("emission", d3),
                 ("fuzz", C.c_double), ("refraction_index", C.c_double), ("tex_type", C.c_int32),
-                ("tex_image", C.c_int32), ("tex_color1", d3), ("tex_color2", d3), ("tex_scale", C.c_double)]
+                ("tex_image", C.c_int32), ("tex_color1", d3), ("tex_color2", d3), ("tex_scale", C.c_double),
+                ("has_normal_map", C.c_int32), ("normal_image", C.c_int32), ("normal_strength", C.c_double)]
 
 
 class Image(C.Structure):

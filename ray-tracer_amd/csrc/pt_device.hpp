@@ -748,6 +748,57 @@ template <class R> RTX_DEV V3<R> albedo_at(const DScene<R>& sc, const DMaterial<
   return mk3(m.c1);
 }
 
+// hit_record::tangent of the winning primitive, as its hit routine writes it (ref: engine/sphere.hpp:39-50,102;
+// engine/primitives.hpp:55-57 plane, :119 triangle, :197-204 box, :310 quad light, :425 disk light).
+template <class R> RTX_DEV V3<R> hit_tangent(const DScene<R>& sc, const Hit<R>& h) {
+  switch (h.type) {
+    case PRIM_SPHERE: {
+      const DSphere<R>& s = sc.spheres[h.idx];
+      const V3<R> on = (h.p - mk3(s.c)) * (R(1) / s.radius);
+      if (abs_(on.y) > R(0.999)) return {R(1), R(0), R(0)};
+      return normalize(V3<R>{-on.z, R(0), on.x});
+    }
+    case PRIM_PLANE: {
+      const V3<R> n = mk3(sc.planes[h.idx].n);
+      const V3<R> up = abs_(n.y) < R(0.999) ? V3<R>{R(0), R(1), R(0)} : V3<R>{R(1), R(0), R(0)};
+      return normalize(cross(up, n));
+    }
+    case PRIM_TRIANGLE: {
+      const DTri<R>& tr = sc.tris[h.idx];
+      return normalize(mk3(tr.v1) - mk3(tr.v0));
+    }
+    case PRIM_BOX: return abs_(h.n.x) > R(0.5) ? V3<R>{R(0), R(0), R(1)} : V3<R>{R(1), R(0), R(0)};
+    case PRIM_QUAD: return normalize(mk3(sc.quads[h.idx].eu));
+    default: return mk3(sc.disks[h.idx].tan);
+  }
+}
+
+// NormalMap::sample (ref: engine/texture.hpp:83-109) and apply_normal_map (ref: engine/renderer.cpp:72-94):
+// replaces the shading normal of `h` by the tangent-space texel carried into the frame (tangent, N x T, N).
+template <class R> RTX_DEV void apply_normal_map(const DScene<R>& sc, const DMaterial<R>& m, Hit<R>& h) {
+  if (m.nmap_image < 0 || m.nmap_image >= sc.n_images) return;
+  const DImage im = sc.images[m.nmap_image];
+  const R u = clamp_(h.u, R(0), R(1));
+  const R v = R(1) - clamp_(h.v, R(0), R(1));
+  int i = (int)(u * R(im.w)), j = (int)(v * R(im.h));
+  i = i < im.w - 1 ? i : im.w - 1; j = j < im.h - 1 ? j : im.h - 1;
+  const uint8_t* t = im.rgb + ((size_t)j * im.w + i) * 3;
+  R nx = (R(t[0]) / R(255)) * R(2) - R(1);
+  R ny = (R(t[1]) / R(255)) * R(2) - R(1);
+  R nz = (R(t[2]) / R(255)) * R(2) - R(1);
+  if (m.nmap_strength < R(1)) {
+    nx = nx * m.nmap_strength;
+    ny = ny * m.nmap_strength;
+    nz = nz * m.nmap_strength + (R(1) - m.nmap_strength);
+  }
+  const V3<R> tn = normalize(V3<R>{nx, ny, nz});
+  const V3<R> N = h.n;
+  V3<R> T = hit_tangent(sc, h);
+  T = normalize(T - N * dot(N, T));
+  const V3<R> B = cross(N, T);
+  h.n = normalize(V3<R>{T.x * tn.x + B.x * tn.y + N.x * tn.z, T.y * tn.x + B.y * tn.y + N.y * tn.z, T.z * tn.x + B.z * tn.y + N.z * tn.z});
+}
+
 template <class R> RTX_DEV R schlick(R cosine, R ref_idx) {
   R r0 = (R(1) - ref_idx) / (R(1) + ref_idx);
   r0 = r0 * r0;
@@ -1037,8 +1088,8 @@ enum : uint32_t { STEP_SHADOW = 1u, STEP_SHADED = 2u };
 // MNEE = true adds manifold next event estimation at Lambertian vertices (ref: engine/renderer.cpp:716-732);
 // it needs `shadow` to return whether the light sample was visible (the reference skips MNEE when an
 // unoccluded sample is rejected, :691/:695) and `trace`, a closest-hit functor (see pt_mnee.hpp).
-template <class R, bool MNEE, class ShadowFn, class TraceFn>
-RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, const Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
+template <class R, bool MNEE, bool NMAP, class ShadowFn, class TraceFn>
+RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
                                   const DRenderParams& P, PathKey key, ShadowFn&& shadow, TraceFn&& trace) {
   const bool nee = P.use_nee != 0, mis = P.use_mis != 0;
   const bool env_is = sc.env.importance != 0;
@@ -1094,6 +1145,7 @@ RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, const Hit<R>
     return did;
   }
   const DMaterial<R>& m = mats[rec.mat];
+  if constexpr (NMAP) apply_normal_map(sc, m, rec);
   V3<R> surf = albedo_at(sc, m, rec);
   if (bounce == 0 || was_spec || !nee) ps.acc = ps.acc + ps.thr * mk3(m.emission);
 
@@ -1193,10 +1245,10 @@ RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, const Hit<R>
   return did;
 }
 
-template <class R, class ShadowFn>
-RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
+template <class R, bool NMAP, class ShadowFn>
+RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
                              const DRenderParams& P, PathKey key, ShadowFn&& shadow) {
-  return path_vertex_impl<R, false>(ps, hit, rec, sc, mats, P, key, shadow, [](const Ray<R>&, R, R, Hit<R>&) { return false; });
+  return path_vertex_impl<R, false, NMAP>(ps, hit, rec, sc, mats, P, key, shadow, [](const Ray<R>&, R, R, Hit<R>&) { return false; });
 }
 
 // Renderer::ray_color_whitted (ref: engine/renderer.cpp:483-569) unrolled into one vertex per call:
@@ -1204,7 +1256,7 @@ RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec
 // answers Scene::is_shadowed (ref: engine/scene.hpp:554-564).  Returns STEP_* and adds the number of shadow
 // queries to `n_shadow`.
 template <class R, class OccFn>
-RTX_DEV uint32_t whitted_vertex(PathState<R>& ps, const bool hit, const Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
+RTX_DEV uint32_t whitted_vertex(PathState<R>& ps, const bool hit, Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
                                 const DRenderParams& P, PathKey key, OccFn&& occluded, uint32_t& n_shadow) {
   const int bounce = (int)(ps.bounce_flags >> 4);
   if (bounce >= P.max_depth) { ps.bounce_flags = 0; return 0u; }   // depth <= 0: black
@@ -1216,6 +1268,7 @@ RTX_DEV uint32_t whitted_vertex(PathState<R>& ps, const bool hit, const Hit<R>& 
     return hit ? STEP_SHADED : 0u;
   }
   const DMaterial<R>& m = mats[rec.mat];
+  apply_normal_map(sc, m, rec);   // ref: engine/renderer.cpp:496
   const V3<R> surf = albedo_at(sc, m, rec);
   const U4 rn = rng_block(key.rng, key.pixel, key.seed, key.sample, 1u + (uint32_t)bounce);
   V3<R> dir;
@@ -1264,7 +1317,7 @@ RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMateria
   if constexpr (INTEG == INTEG_WHITTED) {
     return whitted_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<R>& sr, R t_max) { return trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st); }, extra_shadow);
   } else {
-    return path_vertex_impl<R, INTEG == INTEG_PATH_MNEE>(
+    return path_vertex_impl<R, INTEG == INTEG_PATH_MNEE, MODE == MODE_TREE_UV>(
         ps, hit, rec, sc, mats, P, key,
         [&](const Ray<R>& sr, R t_max, V3<R> contrib) {
           const bool visible = !trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st);

@@ -158,6 +158,7 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
     mats[i].type = m.type; mats[i].has_texture = m.has_texture; mats[i].tex_type = m.tex_type; mats[i].tex_image = m.tex_image;
     cp3(mats[i].albedo, m.albedo); cp3(mats[i].emission, m.emission); mats[i].fuzz = (R)m.fuzz; mats[i].ior = (R)m.refraction_index;
     cp3(mats[i].c1, m.tex_color1); cp3(mats[i].c2, m.tex_color2); mats[i].scale = (R)m.tex_scale;
+    mats[i].nmap_image = m.has_normal_map ? m.normal_image : -1; mats[i].pad = 0; mats[i].nmap_strength = (R)m.normal_strength;
   }
   // Production BVH: the reference tree's topology, boxes in R.  Float boxes are rounded
   // outward; a box that is flat in double stays flat so that the strict slab test rejects it
@@ -346,6 +347,7 @@ int HostScene::upload(const rtx_scene_desc& d, std::string& err) {
     const rtx_material& m = d.materials[i];
     if (m.type < 0 || m.type > 2) { err = "material type out of range"; return RTX_ERR_INVALID_ARGUMENT; }
     if (m.has_texture && m.tex_type == RTX_TEX_IMAGE && (m.tex_image < 0 || (size_t)m.tex_image >= d.n_images)) { err = "material image index out of range"; return RTX_ERR_INVALID_ARGUMENT; }
+    if (m.has_normal_map && (m.normal_image < 0 || (size_t)m.normal_image >= d.n_images)) { err = "material normal map index out of range"; return RTX_ERR_INVALID_ARGUMENT; }
   }
   for (size_t i = 0; i < d.n_images; ++i) if (!d.images[i].rgb || d.images[i].width <= 0 || d.images[i].height <= 0) { err = "bad image"; return RTX_ERR_INVALID_ARGUMENT; }
 

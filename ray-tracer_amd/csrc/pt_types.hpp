@@ -19,7 +19,8 @@ template <class R> struct DDisk { R c[3], n[3]; R radius; R Le[3]; R area; R tan
 
 template <class R> struct DMaterial {
   int32_t type, has_texture, tex_type, tex_image;
-  R albedo[3], emission[3], fuzz, ior, c1[3], c2[3], scale;
+  int32_t nmap_image, pad;   // tangent-space normal map: index into DScene::images, or -1
+  R albedo[3], emission[3], fuzz, ior, c1[3], c2[3], scale, nmap_strength;
 };
 
 struct DImage { const uint8_t* rgb; int32_t w, h; };

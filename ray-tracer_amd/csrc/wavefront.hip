@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene<float> sc, DRenderPara
   PathKey key = {A.pixel[slot], P.seed, A.sample[slot] - 1u, (uint32_t)P.rng};
   Hit<float> rec;
   const bool hit = wf_load_hit<MODE>(sc, A, slot, ps.ray, rec);
-  did = path_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<float>& sr, float t_max, V3<float> contrib) {
+  did = path_vertex<float, MODE == MODE_TREE_UV>(ps, hit, rec, sc, mats, P, key, [&](const Ray<float>& sr, float t_max, V3<float> contrib) {
     cast = true; sh_ray = sr; sh_tmax = t_max; sh_contrib = contrib;
   });
   A.ray[0][slot] = ps.ray.o.x; A.ray[1][slot] = ps.ray.o.y; A.ray[2][slot] = ps.ray.o.z;

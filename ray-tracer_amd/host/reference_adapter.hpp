@@ -61,6 +61,14 @@ template <class SceneT> inline const rtx_scene_desc& to_scene_desc(const SceneT&
       d.tex_image = static_cast<int>(out.images.size());
       out.images.push_back(im);
     }
+    d.has_normal_map = 0; d.normal_image = -1; d.normal_strength = 1.0;
+    if (m.has_normal_map && m.normal_map.valid()) {   // stbi_load(..., 3): always three channels (texture.hpp:61)
+      rtx_image im{m.normal_map.data->data(), m.normal_map.width, m.normal_map.height};
+      d.has_normal_map = 1;
+      d.normal_image = static_cast<int>(out.images.size());
+      d.normal_strength = m.normal_map.strength;
+      out.images.push_back(im);
+    }
     out.materials.push_back(d);
   }
   rtx_scene_desc& d = out.desc;

@@ -306,6 +306,9 @@ def _default_material() -> abi.Material:
     m.tex_color1[:] = (1.0, 1.0, 1.0)
     m.tex_color2[:] = (0.0, 0.0, 0.0)
     m.tex_scale = 1.0
+    m.has_normal_map = 0
+    m.normal_image = -1
+    m.normal_strength = 1.0
     return m
 
 
@@ -422,8 +425,16 @@ def load(path: str, base_dir: str | None = None, image_loader=None) -> SceneData
             inten = float(mat.get("intensity", 1.0))
             m.albedo[:] = c
             m.emission[:] = (e[0] * inten, e[1] * inten, e[2] * inten)
-        if "normal_map" in mat and mat["normal_map"].get("file", ""):
-            data.warnings.append(f"material '{name}': normal_map is not supported by this backend and is ignored")
+        if "normal_map" in mat and mat["normal_map"].get("file", ""):  # scene_loader.hpp:165-172, NormalMap::load (texture.hpp:58-77)
+            fn = mat["normal_map"]["file"]
+            try:
+                img = (image_loader or _load_image_rgb8)(resolve(fn))
+                m.has_normal_map = 1
+                m.normal_image = len(data.images)
+                m.normal_strength = float(mat["normal_map"].get("strength", 1.0))
+                data.images.append(img)
+            except Exception as e:  # a map that fails to load leaves has_normal_map false
+                print(f"Error: Could not load normal map: {fn} ({e})", file=sys.stderr)
         if "roughness_map" in mat and mat["roughness_map"].get("file", ""):
             data.warnings.append(f"material '{name}': roughness_map is not read by the path tracer and is ignored")
         material_ids[name] = len(data.materials)

@@ -193,6 +193,35 @@ def make_mnee_fixtures():
         print("film", tag, float(film.mean()))
 
 
+NORMAL_MAP_FILMS = [("normal_mapped", 32, 18, 4, 12, 111, 1, 1, 0, 1), ("normal_mapped", 24, 14, 3, 12, 112, 1, 0, 0, 1), ("normal_mapped", 24, 14, 3, 12, 113, 0, 0, 0, 1),
+                    ("normal_mapped", 20, 12, 3, 10, 114, 1, 1, 1, 1), ("normal_mapped", 32, 18, 4, 12, 115, 1, 1, 0, 0)]
+
+
+def make_normal_map_fixtures():
+    """The normal-mapped scene (apply_normal_map, engine/renderer.cpp:72-94): loader tables, decoded map texels,
+    closest hits and seeded films in both render modes, with MNEE off and on."""
+    n = "normal_mapped"
+    doc = dump_loader(n)
+    with tempfile.TemporaryDirectory() as td:
+        run(["texels", scene_path(n), os.path.join(td, "t_")])
+        maps = {}
+        for fn in sorted(os.listdir(td)):
+            raw = np.fromfile(os.path.join(td, fn), dtype=np.uint8)
+            w, h = np.frombuffer(raw[:8].tobytes(), dtype=np.int32)
+            maps[fn[2:-4]] = raw[8:].reshape(h, w, 3).copy()
+    np.savez_compressed(os.path.join(HERE, "loader", n + "_texels.npz"), **maps)
+    rays = np.concatenate([camera_rays(doc, 48, 27), random_rays(3000, 19, (0, 1.5, -2), (4, 2, 4))], axis=0)
+    hits = ref_hits(n, rays)
+    np.savez_compressed(os.path.join(HERE, "hits", n + ".npz"), rays=rays, hits=hits)
+    print("hits", n, len(rays), int(hits["hit"].sum()), "maps", sorted(maps))
+    for (n, W, H, spp, depth, seed, nee, mis, mnee, mode) in NORMAL_MAP_FILMS:
+        film, _ = ref_film(n, W, H, spp, depth, seed, nee, mis, mnee=mnee, mode=mode)
+        tag = f"{n}_{W}x{H}_s{spp}_d{depth}_seed{seed}_nee{nee}_mis{mis}" + ("_mnee1" if mnee else "") + ("_whitted" if mode == 0 else "")
+        extra = {"mode": 0} if mode == 0 else {}
+        np.savez_compressed(os.path.join(HERE, "films", tag + ".npz"), film=film, scene=n, W=W, H=H, spp=spp, depth=depth, seed=seed, nee=nee, mis=mis, mnee=mnee, **extra)
+        print("film", tag, float(film.mean()))
+
+
 def rel_mse(x, r):
     x = np.clip(x, 0.0, 1.0); r = np.clip(r, 0.0, 1.0)   # the film Renderer::render returns is clamped
     return float(np.mean((x - r) ** 2 / (r ** 2 + 1e-2)))
@@ -208,6 +237,9 @@ def main():
         return
     if "--whitted-only" in sys.argv:
         make_whitted_fixtures()
+        return
+    if "--normal-only" in sys.argv:
+        make_normal_map_fixtures()
         return
     make_post_fixtures()
     if "--post-only" in sys.argv:
@@ -254,6 +286,7 @@ def main():
 
     make_mnee_fixtures()
     make_whitted_fixtures()
+    make_normal_map_fixtures()
 
     # --- converged references + noise floor ----------------------------------------------
     for n, depth in (("cornell_box", 500), ("cornell_box_quad", 50), ("caustics_test", 16), ("environment_demo", 50), ("kitchen_sink", 24)):

@@ -41,7 +41,7 @@ def check_hits_exact(got, exp):
     assert np.abs(got["u"] - exp["u"]).max() < 1e-12 and np.abs(got["v"] - exp["v"]).max() < 1e-12
 
 
-@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "demo", "kitchen_sink", "textured", "disk_room"])
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "demo", "kitchen_sink", "textured", "disk_room", "normal_mapped"])
 def test_closest_hit_bit_exact_vs_reference(name, tracer, load_scene):
     """Primary-ray (pixel-centre) and random ray sets, incl. zero-component and axis-parallel
     directions: primitive ids and t ordering equal Scene::hit's (engine/scene.hpp:574-674)."""
@@ -92,7 +92,8 @@ def test_edge_cases_empty_and_degenerate(pkg, tracer, load_scene):
 
 @pytest.mark.parametrize("name,nee,mis", [("cornell_box", 1, 1), ("cornell_box", 1, 0), ("cornell_box", 0, 0), ("cornell_box_quad", 1, 1),
                                            ("caustics_test", 1, 1), ("environment_demo", 1, 1), ("environment_demo", 1, 0), ("demo", 1, 1),
-                                           ("kitchen_sink", 1, 1), ("kitchen_sink", 0, 1), ("textured", 1, 1), ("disk_room", 1, 1), ("earth_demo", 1, 1)])
+                                           ("kitchen_sink", 1, 1), ("kitchen_sink", 0, 1), ("textured", 1, 1), ("disk_room", 1, 1), ("earth_demo", 1, 1),
+                                           ("normal_mapped", 1, 1), ("normal_mapped", 1, 0)])
 def test_f64_film_equals_oracle(name, nee, mis, pkg, oracle, tracer, load_scene):
     """Double-precision render vs the CPU oracle driven by the same counter-based sampler: the
     two run the same arithmetic on the same random numbers, so films agree to rounding of the
@@ -118,7 +119,7 @@ def test_f64_film_equals_oracle(name, nee, mis, pkg, oracle, tracer, load_scene)
 
 
 @pytest.mark.parametrize("name,pipe", [("cornell_box", "fused"), ("cornell_box_quad", "fused"), ("environment_demo", "fused"), ("textured", "fused"),
-                                       ("cornell_box", "wavefront"), ("soup", "wavefront")])
+                                       ("cornell_box", "wavefront"), ("soup", "wavefront"), ("normal_mapped", "fused"), ("normal_mapped", "wavefront")])
 def test_f32_pcg_film_equals_oracle_pcg(name, pipe, pkg, oracle, tracer, load_scene):
     """Single precision draws its samples from the pcg4d block generator (RTX_RNG_AUTO).  The oracle fed by the same
     generator renders the same paths in double precision: films agree to single-precision rounding, apart from the
@@ -143,7 +144,7 @@ def test_f32_pcg_film_equals_oracle_pcg(name, pipe, pkg, oracle, tracer, load_sc
     assert (np.abs(other - got) > 1e-3).mean() > 0.2
 
 
-@pytest.mark.parametrize("name", ["demo", "kitchen_points", "textured", "earth_demo", "kitchen_sink"])
+@pytest.mark.parametrize("name", ["demo", "kitchen_points", "textured", "earth_demo", "kitchen_sink", "normal_mapped"])
 def test_whitted_film_equals_oracle(name, pkg, oracle, tracer, load_scene):
     """RenderMode::Whitted (Renderer::ray_color_whitted, engine/renderer.cpp:483-569; the native mode of demo.json and
     earth_demo.json): double precision agrees with the oracle on the same counter-based numbers (the oracle equals the
@@ -166,7 +167,7 @@ def test_whitted_film_equals_oracle(name, pkg, oracle, tracer, load_scene):
     pt.set_settings(sd.settings(precision=pkg.abi.PRECISION_F32, rng=pkg.abi.RNG_PHILOX, **over))   # same numbers as the double run
     f32 = pt.render().astype(np.float64)
     assert pt.last_stats.pipeline_used == pkg.abi.PIPELINE_FUSED and pt.last_stats.samples == W * H * spp
-    if name in ("demo", "textured"):
+    if name in ("demo", "textured", "normal_mapped"):
         # the other scenes have a checker texture on the plane y = 0: floor(y / scale) there is -1 or 0 on the sign of a
         # rounding residue, which differs between precisions over the whole plane (texture.hpp:276-280)
         bad = (np.abs(f32 - got) > 1e-3 * (1.0 + np.abs(got))).any(axis=2)
@@ -178,7 +179,7 @@ def test_whitted_film_equals_oracle(name, pkg, oracle, tracer, load_scene):
         assert got.mean() > 0.05
 
 
-@pytest.mark.parametrize("name,mis", [("cornell_box", 1), ("cornell_box", 0), ("cornell_box_quad", 1), ("caustics_test", 1), ("kitchen_sink", 0), ("disk_room", 1)])
+@pytest.mark.parametrize("name,mis", [("cornell_box", 1), ("cornell_box", 0), ("cornell_box_quad", 1), ("caustics_test", 1), ("kitchen_sink", 0), ("disk_room", 1), ("normal_mapped", 1)])
 def test_mnee_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
     """use_mnee = 1 (the reference's CLI default; MNEE::evaluate, engine/spectral/mnee.hpp:632-763): the render is
     promoted to the double-precision fused kernel and agrees with the oracle run on the same counter-based random
@@ -335,7 +336,7 @@ def test_error_paths(pkg, load_scene):
 
 
 @pytest.mark.parametrize("force_mode", [None, "0", "1"])
-@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "kitchen_sink", "textured", "soup"])
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "kitchen_sink", "textured", "soup", "normal_mapped"])
 def test_wavefront_pipeline_equals_fused(name, force_mode, pkg, tracer, load_scene, monkeypatch):
     """The queue-based pipeline runs the same per-path arithmetic in the same sample order as the
     fused kernel; only instruction selection (multiply-add fusion) may differ between the two

@@ -10,7 +10,7 @@ import pytest
 
 from conftest import GOLDEN, rel_mse, soup_scene
 
-SCENES = ["cornell_box", "cornell_box_quad", "caustics_test", "environment_demo", "earth_demo", "demo", "kitchen_sink", "textured", "disk_room"]
+SCENES = ["cornell_box", "cornell_box_quad", "caustics_test", "environment_demo", "earth_demo", "demo", "kitchen_sink", "textured", "disk_room", "normal_mapped"]
 
 
 def bits(a):
@@ -35,6 +35,10 @@ def test_loader_tables_equal_reference_loader(name, pkg, load_scene):
             if m.tex_type == pkg.abi.TEX_IMAGE:
                 img = sd.images[m.tex_image]
                 assert (img.shape[1], img.shape[0]) == (e["tex_w"], e["tex_h"])
+        assert m.has_normal_map == e["has_normal_map"]
+        if m.has_normal_map:   # NormalMap::load (engine/texture.hpp:58-77)
+            img = sd.images[m.normal_image]
+            assert (img.shape[1], img.shape[0]) == (e["nmap_w"], e["nmap_h"]) and m.normal_strength == e["nmap_strength"]
     assert [(v3(s.center), s.radius, s.material_id) for s in sd.spheres] == [(e["center"], e["radius"], e["material"]) for e in doc["spheres"]]
     assert [(v3(p.point), v3(p.normal), p.material_id) for p in sd.planes] == [(e["point"], e["normal"], e["material"]) for e in doc["planes"]]
     assert [(v3(b.box_min), v3(b.box_max), b.material_id) for b in sd.boxes] == [(e["min"], e["max"], e["material"]) for e in doc["boxes"]]
@@ -60,6 +64,20 @@ def test_loader_tables_equal_reference_loader(name, pkg, load_scene):
         assert sd.env_texels is None
 
 
+def test_normal_map_texels_equal_reference_decoder(load_scene):
+    """The 8-bit texels the loader hands over are the ones the reference's decoder produced (PNG: lossless)."""
+    fx = np.load(os.path.join(GOLDEN, "loader", "normal_mapped_texels.npz"))
+    sd = load_scene("normal_mapped")
+    n_maps = 0
+    for i, m in enumerate(sd.materials):
+        if m.has_normal_map:
+            assert np.array_equal(sd.images[m.normal_image], fx[f"n{i}"])
+            n_maps += 1
+        if m.has_texture and m.tex_type == 2:
+            assert np.array_equal(sd.images[m.tex_image], fx[str(i)])
+    assert n_maps == 5 and sd.materials[6].has_normal_map == 0   # the map that fails to load leaves the material plain
+
+
 def test_material_ids_are_alphabetical(load_scene):
     sd = load_scene("cornell_box")
     assert sd.material_names == ["glass", "green", "light", "metal", "red", "white"]
@@ -83,7 +101,7 @@ def test_env_tables_and_lookup_match_reference(oracle, load_scene):
     assert abs(total - doc["environment"]["total_luminance"]) / total < 1e-12
 
 
-@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "demo", "kitchen_sink", "textured", "disk_room"])
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "demo", "kitchen_sink", "textured", "disk_room", "normal_mapped"])
 def test_closest_hit_bit_exact(name, oracle, load_scene):
     """Scene::hit (engine/scene.hpp:574-674): winner, t, point, normal, u, v — all bits."""
     fx = np.load(os.path.join(GOLDEN, "hits", name + ".npz"))
