@@ -83,7 +83,13 @@ RTX_DEV uint32_t wave_take(uint32_t* cursor, bool want, uint32_t n) {
 // Workgroup-level forms for kernels whose every thread reaches the call (they synchronise the
 // workgroup): ONE atomic per workgroup.  A single hot counter takes a few nanoseconds per
 // atomic at the L2, which at one atomic per wave was most of these kernels' run time.
-struct BlockScratch { uint32_t cnt[kBlock / 64]; uint32_t base; uint32_t sum[2]; };
+#ifndef RTX_STREAM_BLOCK
+#define RTX_STREAM_BLOCK 1024
+#endif
+// Workgroup size of the two streaming kernels (wf_generate, wf_shade): as large as the hardware allows, since each
+// workgroup costs one atomic on the queue's shared counter and those serialise at the L2.
+constexpr int kStreamBlock = RTX_STREAM_BLOCK;
+struct BlockScratch { uint32_t cnt[kStreamBlock / 64]; uint32_t base; uint32_t sum[2]; };
 
 // Entry of the queue for each thread with `want` (0xffffffff for the others).
 RTX_DEV uint32_t block_append(BlockScratch& bs, uint32_t* counter, bool want) {
@@ -94,7 +100,7 @@ RTX_DEV uint32_t block_append(BlockScratch& bs, uint32_t* counter, bool want) {
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t total = 0;
-    for (int k = 0; k < kBlock / 64; ++k) total += bs.cnt[k];
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) total += bs.cnt[k];
     bs.base = total ? atomicAdd(counter, total) : 0u;
   }
   __syncthreads();
@@ -123,7 +129,7 @@ RTX_DEV void block_count2(BlockScratch& bs, unsigned long long* counter_a, bool 
 
 // Slots whose path ended add it to their chunk sum and start the next sample (or take the next
 // (pixel, chunk) work item); every slot that still has a ray to trace goes into the next queue.
-__global__ __launch_bounds__(kBlock) void wf_generate(DCamera<float> cam, DRenderParams P, WfArrays A, WfControl* ctl, int first, int qin, int qout,
+__global__ __launch_bounds__(kStreamBlock) void wf_generate(DCamera<float> cam, DRenderParams P, WfArrays A, WfControl* ctl, int first, int qin, int qout,
                                                       float* __restrict__ partial, DCounters* counters) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = first ? A.n_slots : ctl->n_q[qin];
@@ -277,7 +283,7 @@ template <int MODE> RTX_DEV bool wf_load_hit(const DScene<float>& sc, const WfAr
 }
 
 template <int MODE, bool LDS_MATS>
-__global__ __launch_bounds__(kBlock) void wf_shade(DScene<float> sc, DRenderParams P, WfArrays A, WfControl* ctl, int q, DCounters* counters) {
+__global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DRenderParams P, WfArrays A, WfControl* ctl, int q, DCounters* counters) {
   const DMaterial<float>* mats = sc.mats;
   if constexpr (LDS_MATS) mats = stage_materials(sc);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -379,16 +385,16 @@ template <int MODE> void launch_iteration_kernels(const DScene<float>& sc, const
                                                   float* partial, DCounters* counters, bool lds_mats, size_t mat_lds, int stack_levels, unsigned grid,
                                                   unsigned resident_blocks, int step /*0 first generate, 1 shade, 2 connect, 3 generate*/, int qa, int qb,
                                                   hipStream_t stream, uint32_t& launches, int* spill) {
-  const dim3 g(grid), b(kBlock);
+  const dim3 g((grid + (kStreamBlock / kBlock) - 1) / (kStreamBlock / kBlock)), bs(kStreamBlock), b(kBlock);   // `grid` counts kBlock-sized groups
   const dim3 gw(grid < resident_blocks ? grid : resident_blocks);   // persistent traversal kernels
   const size_t walk_lds = MODE == MODE_FLAT ? 0 : (size_t)stack_levels * kBlock * sizeof(int);
   if (step == 0 || step == 3) {
-    hipLaunchKernelGGL(wf_generate, g, b, 0, stream, cam, P, A, ctl, step == 0 ? 1 : 0, qa, qb, partial, counters);
+    hipLaunchKernelGGL(wf_generate, g, bs, 0, stream, cam, P, A, ctl, step == 0 ? 1 : 0, qa, qb, partial, counters);
     hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, qb, stack_levels, spill);
     ++launches;
   } else if (step == 1) {
-    if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, b, mat_lds, stream, sc, P, A, ctl, qa, counters);
-    else hipLaunchKernelGGL((wf_shade<MODE, false>), g, b, 0, stream, sc, P, A, ctl, qa, counters);
+    if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, P, A, ctl, qa, counters);
+    else hipLaunchKernelGGL((wf_shade<MODE, false>), g, bs, 0, stream, sc, P, A, ctl, qa, counters);
   } else
     hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, stack_levels, spill);
 }
