@@ -4,8 +4,11 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <future>
+#include <mutex>
+#include <thread>
 #include <type_traits>
 
 namespace rtx {
@@ -39,6 +42,21 @@ void WavefrontPool::release() { state.release(); queues.release(); control.relea
 // ------------------------------------------------------------------------------------------
 namespace {
 
+// f(begin, end) over [0, n) on up to 16 host threads (the conversion loops of a large scene).
+template <class F> void parallel_for(size_t n, F&& f) {
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt < 1u ? 1u : nt > 16u ? 16u : nt;
+  if (n < (size_t)1 << 16 || nt == 1u) { f((size_t)0, n); return; }
+  const size_t chunk = (n + nt - 1) / nt;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t) {
+    const size_t b = (size_t)t * chunk, e = b + chunk < n ? b + chunk : n;
+    if (b >= e) break;
+    th.emplace_back([&f, b, e] { f(b, e); });
+  }
+  for (std::thread& t : th) t.join();
+}
+
 struct BuildPrim { double lo[3], hi[3]; int32_t index, type; };
 
 inline double cen(const BuildPrim& p, int ax) { return (p.lo[ax] + p.hi[ax]) * 0.5; }  // ref: bvh.hpp:89-95
@@ -50,24 +68,37 @@ size_t subtree_nodes(size_t count) {
 }
 
 struct Builder {
-  std::vector<BuildPrim>& prims;
-  std::vector<DNodeRef>& nodes;
+  Staging<BuildPrim>& prims;
+  Staging<DNodeRef>& nodes;
 
   void build(size_t me, size_t start, size_t end, int depth) {
     DNodeRef& nd = nodes[me];
     double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};   // ref: bvh.hpp:26-27
-    for (size_t i = start; i < end; ++i)
-      for (int a = 0; a < 3; ++a) {
-        // AABB::expand(other): expand(min) then expand(max), each an fmin + an fmax (bvh.hpp:69-84)
-        lo[a] = std::fmin(std::fmin(lo[a], prims[i].lo[a]), prims[i].hi[a]);
-        hi[a] = std::fmax(std::fmax(hi[a], prims[i].lo[a]), prims[i].hi[a]);
-      }
+    double clo[3] = {1e30, 1e30, 1e30}, chi[3] = {-1e30, -1e30, -1e30};
+    // min / max are exact and order-independent, so a large range is reduced in slices
+    auto bounds = [&](size_t b, size_t e, double* lo, double* hi, double* clo, double* chi) {
+      for (size_t i = b; i < e; ++i)
+        for (int a = 0; a < 3; ++a) {
+          // AABB::expand(other): expand(min) then expand(max), each an fmin + an fmax (bvh.hpp:69-84)
+          lo[a] = std::fmin(std::fmin(lo[a], prims[i].lo[a]), prims[i].hi[a]);
+          hi[a] = std::fmax(std::fmax(hi[a], prims[i].lo[a]), prims[i].hi[a]);
+          double c = cen(prims[i], a); clo[a] = std::fmin(clo[a], c); chi[a] = std::fmax(chi[a], c);
+        }
+    };
+    if (end - start > ((size_t)1 << 20)) {
+      std::mutex mu;
+      parallel_for(end - start, [&](size_t b, size_t e) {
+        double l[3] = {1e30, 1e30, 1e30}, h[3] = {-1e30, -1e30, -1e30}, cl[3] = {1e30, 1e30, 1e30}, ch[3] = {-1e30, -1e30, -1e30};
+        bounds(start + b, start + e, l, h, cl, ch);
+        std::lock_guard<std::mutex> g(mu);
+        for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], l[a]); hi[a] = std::fmax(hi[a], h[a]); clo[a] = std::fmin(clo[a], cl[a]); chi[a] = std::fmax(chi[a], ch[a]); }
+      });
+    } else {
+      bounds(start, end, lo, hi, clo, chi);
+    }
     for (int a = 0; a < 3; ++a) { nd.lo[a] = lo[a]; nd.hi[a] = hi[a]; }
     size_t count = end - start;
     if (count <= 2) { nd.left = -1; nd.right = -1; nd.first = (int32_t)start; nd.count = (int32_t)count; return; }
-    double clo[3] = {1e30, 1e30, 1e30}, chi[3] = {-1e30, -1e30, -1e30};
-    for (size_t i = start; i < end; ++i)
-      for (int a = 0; a < 3; ++a) { double c = cen(prims[i], a); clo[a] = std::fmin(clo[a], c); chi[a] = std::fmax(chi[a], c); }
     double dx = chi[0] - clo[0], dy = chi[1] - clo[1], dz = chi[2] - clo[2];
     int axis = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);   // ref: bvh.hpp:100-107
     size_t mid = start + count / 2;
@@ -75,7 +106,7 @@ struct Builder {
                      [axis](const BuildPrim& a, const BuildPrim& b) { return cen(a, axis) < cen(b, axis); });
     size_t left = me + 1, right = me + 1 + subtree_nodes(mid - start);
     nd.left = (int32_t)left; nd.right = (int32_t)right; nd.first = 0; nd.count = 0;
-    if (count > 32768 && depth < 4) {
+    if (count > 32768 && depth < 6) {
       auto fut = std::async(std::launch::async, [=] { build(left, start, mid, depth + 1); });
       build(right, mid, end, depth + 1);
       fut.get();
@@ -92,7 +123,7 @@ float f_up(double v) { float f = (float)v; if ((double)f < v) f = std::nextafter
 
 template <class T, class S> void cp3(T* dst, const S* src) { dst[0] = (T)src[0]; dst[1] = (T)src[1]; dst[2] = (T)src[2]; }
 
-template <class T> const T* push(std::vector<DeviceBuffer>& pool, const std::vector<T>& v, bool& ok) {
+template <class T, class A> const T* push(std::vector<DeviceBuffer>& pool, const std::vector<T, A>& v, bool& ok) {
   pool.emplace_back();
   if (!pool.back().upload(v.data(), v.size() * sizeof(T))) ok = false;
   return (const T*)pool.back().ptr;
@@ -134,8 +165,19 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
   for (size_t i = 0; i < d.n_spheres; ++i) { cp3(sph[i].c, d.spheres[i].center); sph[i].radius = (R)d.spheres[i].radius; sph[i].mat = d.spheres[i].material_id; sph[i].pad = 0; }
   std::vector<DPlane<R>> pls(d.n_planes);
   for (size_t i = 0; i < d.n_planes; ++i) { cp3(pls[i].p, d.planes[i].point); cp3(pls[i].n, d.planes[i].normal); pls[i].mat = d.planes[i].material_id; pls[i].pad = 0; }
-  std::vector<DTri<R>> tris(d.n_triangles);
-  for (size_t i = 0; i < d.n_triangles; ++i) { cp3(tris[i].v0, d.triangles[i].v0); cp3(tris[i].v1, d.triangles[i].v1); cp3(tris[i].v2, d.triangles[i].v2); tris[i].mat = d.triangles[i].material_id; tris[i].pad = 0; }
+  // rtx_triangle and DTri<double> have the same layout: the double-precision scene takes the caller's array as it is
+  static_assert(sizeof(DTri<double>) == sizeof(rtx_triangle) && offsetof(DTri<double>, mat) == offsetof(rtx_triangle, material_id), "layout");
+  Staging<DTri<R>> tris;
+  if constexpr (std::is_same<R, double>::value) {
+    pool.emplace_back();
+    if (!pool.back().upload(d.triangles, d.n_triangles * sizeof(rtx_triangle))) ok = false;
+    sc.tris = (const DTri<R>*)pool.back().ptr;
+  } else {
+    tris.resize(d.n_triangles);
+    parallel_for(d.n_triangles, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) { cp3(tris[i].v0, d.triangles[i].v0); cp3(tris[i].v1, d.triangles[i].v1); cp3(tris[i].v2, d.triangles[i].v2); tris[i].mat = d.triangles[i].material_id; tris[i].pad = 0; }
+    });
+  }
   std::vector<DBox<R>> boxes(d.n_boxes);
   for (size_t i = 0; i < d.n_boxes; ++i) { cp3(boxes[i].lo, d.boxes[i].box_min); cp3(boxes[i].hi, d.boxes[i].box_max); boxes[i].mat = d.boxes[i].material_id; boxes[i].pad = 0; }
   std::vector<DPoint<R>> pts(d.n_point_lights);
@@ -163,22 +205,24 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
   // Production BVH: the reference tree's topology, boxes in R.  Float boxes are rounded
   // outward; a box that is flat in double stays flat so that the strict slab test rejects it
   // exactly as the reference's does (a leaf of axis-aligned coplanar triangles is never hit there).
-  std::vector<DNode2<R>> nodes(bvh.nodes.size());
-  for (size_t i = 0; i < bvh.nodes.size(); ++i) {
-    const DNodeRef& n = bvh.nodes[i];
-    for (int a = 0; a < 3; ++a) {
-      if (std::is_same<R, float>::value && n.lo[a] != n.hi[a]) { nodes[i].lo[a] = (R)f_down(n.lo[a]); nodes[i].hi[a] = (R)f_up(n.hi[a]); }
-      else { nodes[i].lo[a] = (R)n.lo[a]; nodes[i].hi[a] = (R)n.hi[a]; }
+  Staging<DNode2<R>> nodes(bvh.nodes.size());
+  parallel_for(bvh.nodes.size(), [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      const DNodeRef& n = bvh.nodes[i];
+      for (int a = 0; a < 3; ++a) {
+        if (std::is_same<R, float>::value && n.lo[a] != n.hi[a]) { nodes[i].lo[a] = (R)f_down(n.lo[a]); nodes[i].hi[a] = (R)f_up(n.hi[a]); }
+        else { nodes[i].lo[a] = (R)n.lo[a]; nodes[i].hi[a] = (R)n.hi[a]; }
+      }
+      if (n.count > 0) { nodes[i].a = n.first; nodes[i].count = n.count; }
+      else { nodes[i].a = n.right; nodes[i].count = 0; }
     }
-    if (n.count > 0) { nodes[i].a = n.first; nodes[i].count = n.count; }
-    else { nodes[i].a = n.right; nodes[i].count = 0; }
-  }
+  });
   if (std::is_same<R, float>::value && bvh.prims.size() > (size_t)kLinearMaxPrims) {
     // child-pair records, one per inner node, in the order the inner nodes appear in preorder
-    std::vector<int32_t> pair_of(bvh.nodes.size(), -1);
+    Staging<int32_t> pair_of(bvh.nodes.size());   // read for inner nodes only
     int32_t np = 0;
     for (size_t i = 0; i < bvh.nodes.size(); ++i) if (bvh.nodes[i].count == 0) pair_of[i] = np++;
-    std::vector<DNodePair> pairs((size_t)np);
+    Staging<DNodePair> pairs((size_t)np);
     auto code = [&](int32_t child) -> int32_t {
       const DNodeRef& c = bvh.nodes[child];
       return c.count > 0 ? ~((c.first << 2) | c.count) : pair_of[child];
@@ -190,44 +234,47 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
         else { lo[a] = (float)c.lo[a]; hi[a] = (float)c.hi[a]; }
       }
     };
-    for (size_t i = 0; i < bvh.nodes.size(); ++i) {
-      const DNodeRef& n = bvh.nodes[i];
-      if (n.count > 0) continue;
-      DNodePair& p = pairs[(size_t)pair_of[i]];
-      box(n.left, p.lo_l, p.hi_l); box(n.right, p.lo_r, p.hi_r);
-      p.cl = code(n.left); p.cr = code(n.right); p.pad0 = p.pad1 = 0;
-    }
-    std::vector<DLeafPrim> leaf(bvh.prims.size());
-    for (size_t i = 0; i < bvh.prims.size(); ++i) {
-      DLeafPrim& l = leaf[i];
-      memset(&l, 0, sizeof l);
-      l.type = bvh.prims[i].type; l.index = bvh.prims[i].index;
-      if (l.type == PRIM_TRIANGLE) {
-        const rtx_triangle& t = d.triangles[l.index];
-        cp3(l.v0, t.v0); cp3(l.v1, t.v1); cp3(l.v2, t.v2); l.mat = t.material_id;
+    parallel_for(bvh.nodes.size(), [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        const DNodeRef& n = bvh.nodes[i];
+        if (n.count > 0) continue;
+        DNodePair& p = pairs[(size_t)pair_of[i]];
+        box(n.left, p.lo_l, p.hi_l); box(n.right, p.lo_r, p.hi_r);
+        p.cl = code(n.left); p.cr = code(n.right); p.pad0 = p.pad1 = 0;
       }
-    }
-    sc.pairs = push(pool, pairs, ok); sc.leaf_prims = push(pool, leaf, ok); sc.n_pairs = np;
-    // four-wide records: an inner node's children, each replaced by ITS children when it is inner
-    std::vector<int32_t> wide_of(bvh.nodes.size(), -1);
-    std::vector<int32_t> wide_nodes;   // binary node of every wide record, in creation order
-    {
-      std::vector<int32_t> todo{0};
-      wide_of[0] = 0; wide_nodes.push_back(0);
-      for (size_t head = 0; head < wide_nodes.size(); ++head) {
-        const DNodeRef& n = bvh.nodes[(size_t)wide_nodes[head]];
-        const int32_t kids[2] = {n.left, n.right};
-        for (int32_t k : kids) {
-          const DNodeRef& c = bvh.nodes[(size_t)k];
-          if (c.count > 0) continue;
-          const int32_t grand[2] = {c.left, c.right};
-          for (int32_t g : grand)
-            if (bvh.nodes[(size_t)g].count == 0) { wide_of[(size_t)g] = (int32_t)wide_nodes.size(); wide_nodes.push_back(g); }
+    });
+    Staging<DLeafPrim> leaf(bvh.prims.size());
+    parallel_for(bvh.prims.size(), [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        DLeafPrim& l = leaf[i];
+        memset(&l, 0, sizeof l);
+        l.type = bvh.prims[i].type; l.index = bvh.prims[i].index;
+        if (l.type == PRIM_TRIANGLE) {
+          const rtx_triangle& t = d.triangles[l.index];
+          cp3(l.v0, t.v0); cp3(l.v1, t.v1); cp3(l.v2, t.v2); l.mat = t.material_id;
         }
       }
+    });
+    sc.pairs = push(pool, pairs, ok); sc.leaf_prims = push(pool, leaf, ok); sc.n_pairs = np;
+    // four-wide records: an inner node's children, each replaced by ITS children when it is inner
+    // An inner node at even depth starts a wide record.  The nodes are in preorder, so one forward pass hands the depth
+    // parity down and numbers the records.
+    Staging<int32_t> wide_of(bvh.nodes.size());
+    std::vector<int32_t> wide_nodes;   // binary node of every wide record, in record order
+    {
+      Staging<uint8_t> odd(bvh.nodes.size());
+      odd[0] = 0;
+      wide_nodes.reserve(bvh.nodes.size() / 6 + 16);
+      for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+        const DNodeRef& n = bvh.nodes[i];
+        if (n.count > 0) continue;
+        if (!odd[i]) { wide_of[i] = (int32_t)wide_nodes.size(); wide_nodes.push_back((int32_t)i); }
+        odd[(size_t)n.left] = odd[(size_t)n.right] = (uint8_t)(odd[i] ^ 1);
+      }
     }
-    std::vector<DNodeWide> wide(wide_nodes.size());
-    for (size_t w = 0; w < wide_nodes.size(); ++w) {
+    Staging<DNodeWide> wide(wide_nodes.size());
+    parallel_for(wide_nodes.size(), [&](size_t wb, size_t we) {
+    for (size_t w = wb; w < we; ++w) {
       DNodeWide& q = wide[w];
       memset(&q, 0, sizeof q);
       for (int k = 0; k < 4; ++k) q.child[k] = kWideEmpty;
@@ -249,6 +296,7 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
         else { add(c.left); add(c.right); }
       }
     }
+    });
     sc.wide = push(pool, wide, ok); sc.n_wide = (int32_t)wide.size();
   }
   if (std::is_same<R, float>::value && d.n_triangles == 0 && d.n_boxes == 0 && d.n_spheres <= (size_t)kFlatMaxSpheres) {
@@ -263,7 +311,8 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
     for (size_t i = 0; i < d.n_disk_lights; ++i) rec((float)d.disk_lights[i].normal[0], (float)d.disk_lights[i].normal[1], (float)d.disk_lights[i].normal[2], 0.f, -1000 - (int)i, PRIM_DISK, (int)i);
     sc.flat = push(pool, recs, ok);
   }
-  sc.spheres = push(pool, sph, ok); sc.planes = push(pool, pls, ok); sc.tris = push(pool, tris, ok); sc.boxes = push(pool, boxes, ok);
+  sc.spheres = push(pool, sph, ok); sc.planes = push(pool, pls, ok); sc.boxes = push(pool, boxes, ok);
+  if constexpr (!std::is_same<R, double>::value) sc.tris = push(pool, tris, ok);
   sc.points = push(pool, pts, ok); sc.quads = push(pool, quads, ok); sc.disks = push(pool, disks, ok); sc.mats = push(pool, mats, ok);
   sc.nodes = push(pool, nodes, ok);
   sc.emissive = push(pool, emissive, ok);
@@ -287,33 +336,32 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
 void HostBvh::build(const rtx_scene_desc& d) {
   auto t0 = std::chrono::steady_clock::now();
   nodes.clear(); prims.clear();
-  std::vector<BuildPrim> bp;
-  bp.reserve(d.n_spheres + d.n_triangles + d.n_boxes);
-  for (size_t i = 0; i < d.n_spheres; ++i) {   // ref: engine/scene.hpp:500-510
-    BuildPrim p; p.type = PRIM_SPHERE; p.index = (int32_t)i;
+  const size_t ns = d.n_spheres, nt = d.n_triangles, nb = d.n_boxes;
+  Staging<BuildPrim> bp(ns + nt + nb);
+  for (size_t i = 0; i < ns; ++i) {   // ref: engine/scene.hpp:500-510
+    BuildPrim& p = bp[i]; p.type = PRIM_SPHERE; p.index = (int32_t)i;
     for (int a = 0; a < 3; ++a) { p.lo[a] = d.spheres[i].center[a] - d.spheres[i].radius; p.hi[a] = d.spheres[i].center[a] + d.spheres[i].radius; }
-    bp.push_back(p);
   }
-  for (size_t i = 0; i < d.n_triangles; ++i) {  // ref: engine/scene.hpp:513-522
-    BuildPrim p; p.type = PRIM_TRIANGLE; p.index = (int32_t)i;
-    const rtx_triangle& t = d.triangles[i];
-    for (int a = 0; a < 3; ++a) {
-      p.lo[a] = std::fmin(std::fmin(std::fmin(1e30, t.v0[a]), t.v1[a]), t.v2[a]);
-      p.hi[a] = std::fmax(std::fmax(std::fmax(-1e30, t.v0[a]), t.v1[a]), t.v2[a]);
+  parallel_for(nt, [&](size_t b, size_t e) {   // ref: engine/scene.hpp:513-522
+    for (size_t i = b; i < e; ++i) {
+      BuildPrim& p = bp[ns + i]; p.type = PRIM_TRIANGLE; p.index = (int32_t)i;
+      const rtx_triangle& t = d.triangles[i];
+      for (int a = 0; a < 3; ++a) {
+        p.lo[a] = std::fmin(std::fmin(std::fmin(1e30, t.v0[a]), t.v1[a]), t.v2[a]);
+        p.hi[a] = std::fmax(std::fmax(std::fmax(-1e30, t.v0[a]), t.v1[a]), t.v2[a]);
+      }
     }
-    bp.push_back(p);
-  }
-  for (size_t i = 0; i < d.n_boxes; ++i) {      // ref: engine/scene.hpp:525-533
-    BuildPrim p; p.type = PRIM_BOX; p.index = (int32_t)i;
+  });
+  for (size_t i = 0; i < nb; ++i) {      // ref: engine/scene.hpp:525-533
+    BuildPrim& p = bp[ns + nt + i]; p.type = PRIM_BOX; p.index = (int32_t)i;
     for (int a = 0; a < 3; ++a) { p.lo[a] = d.boxes[i].box_min[a]; p.hi[a] = d.boxes[i].box_max[a]; }
-    bp.push_back(p);
   }
   if (!bp.empty()) {
     nodes.resize(subtree_nodes(bp.size()));
     Builder b{bp, nodes};
     b.build(0, 0, bp.size(), 0);
     prims.resize(bp.size());
-    for (size_t i = 0; i < bp.size(); ++i) { prims[i].type = bp[i].type; prims[i].index = bp[i].index; }
+    parallel_for(bp.size(), [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) { prims[i].type = bp[i].type; prims[i].index = bp[i].index; } });
   }
   seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -351,8 +399,18 @@ int HostScene::upload(const rtx_scene_desc& d, std::string& err) {
   }
   for (size_t i = 0; i < d.n_images; ++i) if (!d.images[i].rgb || d.images[i].width <= 0 || d.images[i].height <= 0) { err = "bad image"; return RTX_ERR_INVALID_ARGUMENT; }
 
+  const bool timing = getenv("RTX_TIMING") != nullptr;   // diagnostics: phase times of the upload on stderr
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[rtx upload] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
+  lap("validate");
   HostBvh bvh;
   bvh.build(d);
+  lap("bvh build");
   build_seconds = bvh.seconds;
   n_nodes = (int)bvh.nodes.size(); n_prims = (int)bvh.prims.size();
 
@@ -383,8 +441,11 @@ int HostScene::upload(const rtx_scene_desc& d, std::string& err) {
     if (!pool.back().upload(e->rgb, (size_t)e->width * e->height * 3 * sizeof(float))) ok = false;
     d_env = (const float*)pool.back().ptr;
   }
+  lap("images, reference tree, env");
   fill_scene(dev_d, pool, d, bvh, emissive, d_images, d_prims, d_env, marginal, conditional, env_total, ok);
+  lap("double-precision scene");
   fill_scene(dev_f, pool, d, bvh, emissive, d_images, d_prims, d_env, marginal, conditional, env_total, ok);
+  lap("single-precision scene");
   dev_ref.nodes = d_nodes_ref; dev_ref.prims = d_prims; dev_ref.n_nodes = n_nodes; dev_ref.n_prims = n_prims;
   if (!ok) { release(); err = "device allocation or copy failed"; return RTX_ERR_OUT_OF_MEMORY; }
   return RTX_OK;

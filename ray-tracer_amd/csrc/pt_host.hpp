@@ -4,7 +4,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <memory>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/rtx_hip.h"
@@ -20,11 +23,20 @@ struct DeviceBuffer {
   void release();
 };
 
+// Allocator whose construct() default-initialises: a std::vector of PODs built with it does not zero its
+// storage, so the pages of a large staging array are first touched by the threads that fill it.
+template <class T> struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+  template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using Staging = std::vector<T, NoInitAlloc<T>>;
+
 // The reference-order BVH on the host (ref: engine/bvh.hpp:148-218 over the primitive list
 // of engine/scene.hpp:496-533).
 struct HostBvh {
-  std::vector<DNodeRef> nodes;
-  std::vector<DPrimRef> prims;
+  Staging<DNodeRef> nodes;
+  Staging<DPrimRef> prims;
   double seconds = 0.0;
   void build(const rtx_scene_desc& d);
 };
