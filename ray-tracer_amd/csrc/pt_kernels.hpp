@@ -58,11 +58,14 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #ifndef RTX_LEAN_MIN_WAVES
 #define RTX_LEAN_MIN_WAVES 6
 #endif
+#ifndef RTX_MNEE_MIN_WAVES
+#define RTX_MNEE_MIN_WAVES 3   // manifold NEE instance (double precision): measured 1: 330 ms, 2: 240, 3: 219, 4: 263 (cornell_box_quad 800x800x16)
+#endif
 // LEAN (bit mask) compiles scene features out of an instance by pinning the scene's counts to zero, so that every
 // branch on them folds away: 1 = no environment map, 2 = no point and no disk lights, 4 = no quad lights,
 // 8 = NEE and MIS on, 16 = the pcg4d generator.
 template <class R, int MODE, bool LDS_MATS, int INTEG = INTEG_PATH, int LEAN = 0>
-__global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? ((LEAN & 1) ? RTX_LEAN_MIN_WAVES : (LEAN ? RTX_LEAN_ENV_MIN_WAVES : RTX_FLAT_MIN_WAVES)) : 1)) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
+__global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? ((LEAN & 1) ? RTX_LEAN_MIN_WAVES : (LEAN ? RTX_LEAN_ENV_MIN_WAVES : RTX_FLAT_MIN_WAVES)) : (INTEG == INTEG_PATH_MNEE ? RTX_MNEE_MIN_WAVES : 1))) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
                                                                DCounters* __restrict__ counters, int stack_first_int) {
   if constexpr ((LEAN & 1) != 0) { sc.env.valid = 0; sc.env.importance = 0; }
   if constexpr ((LEAN & 2) != 0) { sc.n_points = 0; sc.n_disks = 0; }

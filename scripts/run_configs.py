@@ -1,6 +1,6 @@
 """Runs the measurement configurations C1-C5 once each on cuda:0 and prints one JSON line per run.
 
-  python scripts/run_configs.py [c2 c3 c4 c5 ...] [--repeat N]
+  python scripts/run_configs.py [c2 c3 c4 c5 ...] [--repeat N] [--spp N] [--pipeline auto|fused|wavefront] [--mnee] [--f64]
 C4 at its full 3840x2160x4096 size takes several seconds per scene; C5 builds a 10 M triangle scene."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,7 +36,7 @@ def main():
                 t0 = time.time(); pt.upload_scene(sd); t_upload = time.time() - t0
                 info = pt.bvh_info() if hasattr(pt, "bvh_info") else None
                 pt.set_camera(sd.camera(over["width"], over["height"]))
-                pt.set_settings(sd.settings(use_nee=1, use_mis=1, use_mnee=int('--mnee' in sys.argv), pipeline=pipe, **over))
+                pt.set_settings(sd.settings(use_nee=1, use_mis=1, use_mnee=int('--mnee' in sys.argv), pipeline=pipe, precision=abi.PRECISION_F64 if '--f64' in sys.argv else abi.PRECISION_F32, **over))
                 best = None
                 for _ in range(repeat):
                     film = pt.render(); st = pt.last_stats
