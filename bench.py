@@ -75,11 +75,19 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     stats = []
+    gather_events = []   # rank 0, N > 1: the film gather of every timed step, bracketed by events on torch's stream
 
     def step():
         s = pt.render_device(local.data_ptr(), stream)   # kernels on torch's current stream; returns when they are done
         stats.append((s.samples, s.rays_closest, s.rays_shadow, s.segments, s.seconds_main_kernel, s.seconds_render))
-        return parallel.gather_film(local, H, W, rank, world)
+        if world == 1:
+            return parallel.gather_film(local, H, W, rank, world)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        full = parallel.gather_film(local, H, W, rank, world)
+        e1.record()
+        gather_events.append((e0, e1))
+        return full
 
     def fence():
         if world > 1:
@@ -90,6 +98,7 @@ def main():
     for _ in range(args.warmup):
         film = step()
     stats.clear()
+    gather_events.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -166,6 +175,12 @@ def main():
                          "kernel": "render_fused_kernel<float>" if pt.last_stats.pipeline_used == abi.PIPELINE_FUSED else "wavefront iteration kernels",
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if world > 1 and gather_events:
+            # rank 0's view: waiting for the slowest rank + the transfers + re-interleaving the rows
+            g_ms = sum(a.elapsed_time(b) for a, b in gather_events) / len(gather_events)
+            into_root = (world - 1) * parallel.shard_rows(H, 0, world) * W * 3 * 4
+            out["film_gather"] = {"ms_per_step_incl_wait": g_ms, "bytes_into_rank0": into_root,
+                                  "GBps_lower_bound": into_root / (g_ms * 1e-3) / 1e9 if g_ms > 0 else None}
         if world == 1 and args.cpu_baseline_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pkg, sd, args)
         print(json.dumps(out), flush=True)
