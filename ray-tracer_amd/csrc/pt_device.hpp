@@ -488,6 +488,11 @@ constexpr int kWalkDone = 0x7fffffff;
 
 RTX_DEV void pair_walk_begin(PairWalk& w, const Ray<float>& r) {
   w.inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+#if RTX_WIDE_QUANT
+  // the quantised records multiply 1/d by box units: keep it finite (a component below 1e-18 moves the ray by less
+  // than 1e-9 over the longest ray, so the slab of that axis is constant along it either way)
+  w.inv = {fminf(fmaxf(w.inv.x, -1e18f), 1e18f), fminf(fmaxf(w.inv.y, -1e18f), 1e18f), fminf(fmaxf(w.inv.z, -1e18f), 1e18f)};
+#endif
   w.node = 0; w.sp = 0; w.rank = -1;
 }
 RTX_DEV bool pair_walk_at_inner(const PairWalk& w) { return w.node >= 0 && w.node != kWalkDone; }
@@ -496,8 +501,28 @@ RTX_DEV bool pair_walk_at_leaf(const PairWalk& w) { return w.node < 0; }
 // One four-wide record: test the (up to) four boxes, continue with the nearest child that was
 // entered and park the others on the stack, farthest first.
 RTX_DEV void pair_walk_inner(const DScene<float>& sc, const Ray<float>& r, float t_min, const Cand<float>& c, PairWalk& w, LaneStack st) {
-  const DNodeWide q = sc.wide[w.node];
   float e[4]; int ch[4];
+#if RTX_WIDE_QUANT
+  const DNodeWideQ q = sc.wideq[w.node];
+  // slab distance of a quantised plane v:  (org + v * unit - o) / d  =  v * (unit / d) + (org - o) / d
+  const float ux = __uint_as_float((q.exps & 0xffu) << 23), uy = __uint_as_float(((q.exps >> 8) & 0xffu) << 23), uz = __uint_as_float(((q.exps >> 16) & 0xffu) << 23);
+  const float ax = ux * w.inv.x, ay = uy * w.inv.y, az = uz * w.inv.z;
+  const float bx = (q.org[0] - r.o.x) * w.inv.x, by = (q.org[1] - r.o.y) * w.inv.y, bz = (q.org[2] - r.o.z) * w.inv.z;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float t0 = fmaf((float)((q.qlo[0] >> (8 * k)) & 0xffu), ax, bx), t1 = fmaf((float)((q.qhi[0] >> (8 * k)) & 0xffu), ax, bx);
+    float a = fminf(t0, t1), b = fmaxf(t0, t1);
+    t0 = fmaf((float)((q.qlo[1] >> (8 * k)) & 0xffu), ay, by); t1 = fmaf((float)((q.qhi[1] >> (8 * k)) & 0xffu), ay, by);
+    a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
+    t0 = fmaf((float)((q.qlo[2] >> (8 * k)) & 0xffu), az, bz); t1 = fmaf((float)((q.qhi[2] >> (8 * k)) & 0xffu), az, bz);
+    a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
+    a = fmaxf(a, t_min); b = fminf(b, c.t);
+    const bool ok = a < b && q.child[k] != kWideEmpty;
+    e[k] = ok ? a : 3.0e38f;
+    ch[k] = ok ? q.child[k] : kWalkDone;
+  }
+#else
+  const DNodeWide q = sc.wide[w.node];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float t0 = (q.lo_x[k] - r.o.x) * w.inv.x, t1 = (q.hi_x[k] - r.o.x) * w.inv.x;
@@ -511,6 +536,7 @@ RTX_DEV void pair_walk_inner(const DScene<float>& sc, const Ray<float>& r, float
     e[k] = ok ? a : 3.0e38f;
     ch[k] = ok ? q.child[k] : kWalkDone;
   }
+#endif
   // sorting network on (entry distance, child): ascending
 #define RTX_CSWAP(i, j) { const bool s_ = e[j] < e[i]; const float te = s_ ? e[j] : e[i]; const float tf = s_ ? e[i] : e[j]; \
                           const int tc = s_ ? ch[j] : ch[i]; const int td = s_ ? ch[i] : ch[j]; e[i] = te; e[j] = tf; ch[i] = tc; ch[j] = td; }

@@ -272,6 +272,58 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
         odd[(size_t)n.left] = odd[(size_t)n.right] = (uint8_t)(odd[i] ^ 1);
       }
     }
+#if RTX_WIDE_QUANT
+    Staging<DNodeWideQ> wideq(wide_nodes.size());
+    parallel_for(wide_nodes.size(), [&](size_t wb, size_t we) {
+    for (size_t w = wb; w < we; ++w) {
+      DNodeWideQ& q = wideq[w];
+      memset(&q, 0, sizeof q);
+      float lo[4][3], hi[4][3];
+      int32_t kid[4];
+      int used = 0;
+      auto add = [&](int32_t node) {
+        const DNodeRef& c = bvh.nodes[(size_t)node];
+        box(node, lo[used], hi[used]);
+        const bool flat = c.lo[0] == c.hi[0] || c.lo[1] == c.hi[1] || c.lo[2] == c.hi[2];
+        kid[used] = flat ? kWideEmpty : (c.count > 0 ? ~((c.first << 2) | c.count) : wide_of[(size_t)node]);
+        ++used;
+      };
+      const DNodeRef& n = bvh.nodes[(size_t)wide_nodes[w]];
+      const int32_t kids[2] = {n.left, n.right};
+      for (int32_t k : kids) {
+        const DNodeRef& c = bvh.nodes[(size_t)k];
+        if (c.count > 0) add(k);
+        else { add(c.left); add(c.right); }
+      }
+      for (int k = 0; k < 4; ++k) q.child[k] = k < used ? kid[k] : kWideEmpty;
+      for (int a = 0; a < 3; ++a) {
+        float plo = INFINITY, phi = -INFINITY;
+        for (int k = 0; k < used; ++k) if (kid[k] != kWideEmpty) { plo = std::fmin(plo, lo[k][a]); phi = std::fmax(phi, hi[k][a]); }
+        if (!(plo <= phi)) { plo = 0.f; phi = 0.f; }   // no live child
+        q.org[a] = plo;
+        // unit 2^e with 255 units covering the extent; the loop settles what float rounding leaves open
+        int e = -126;
+        const double ext = (double)phi - (double)plo;
+        if (ext > 0.0) { (void)std::frexp(ext / 255.0, &e); if (e < -126) e = -126; }
+        while (e < 127 && std::ceil(ext / std::ldexp(1.0, e)) > 255.0) ++e;
+        const double unit = std::ldexp(1.0, e);
+        q.exps |= (uint32_t)(e + 127) << (8 * a);
+        uint32_t ql = 0, qh = 0;
+        for (int k = 0; k < 4; ++k) {
+          int l = 255, h = 0;   // an empty child: inverted, never entered
+          if (k < used && kid[k] != kWideEmpty) {
+            l = (int)std::floor(((double)lo[k][a] - (double)plo) / unit);
+            h = (int)std::ceil(((double)hi[k][a] - (double)plo) / unit);
+            l = l < 0 ? 0 : l; h = h > 255 ? 255 : h;
+          }
+          ql |= (uint32_t)l << (8 * k); qh |= (uint32_t)h << (8 * k);
+        }
+        q.qlo[a] = ql; q.qhi[a] = qh;
+      }
+    }
+    });
+    sc.wideq = push(pool, wideq, ok); sc.n_wide = (int32_t)wideq.size();
+#else
     Staging<DNodeWide> wide(wide_nodes.size());
     parallel_for(wide_nodes.size(), [&](size_t wb, size_t we) {
     for (size_t w = wb; w < we; ++w) {
@@ -298,6 +350,7 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
     }
     });
     sc.wide = push(pool, wide, ok); sc.n_wide = (int32_t)wide.size();
+#endif
   }
   if (std::is_same<R, float>::value && d.n_triangles == 0 && d.n_boxes == 0 && d.n_spheres <= (size_t)kFlatMaxSpheres) {
     std::vector<DFlatRec> recs;

@@ -44,6 +44,15 @@ struct alignas(16) DNodePair { float lo_l[3], hi_l[3], lo_r[3], hi_r[3]; int32_t
 // component-wise.  child[k]: >= 0 another record, < 0 a leaf code as above, kWideEmpty = unused.
 struct alignas(16) DNodeWide { float lo_x[4], lo_y[4], lo_z[4], hi_x[4], hi_y[4], hi_z[4]; int32_t child[4]; int32_t pad[4]; };
 constexpr int32_t kWideEmpty = 0x7ffffffe;
+// The same record in 64 bytes (half a cache line per traversal step instead of a whole one): the four boxes as 8-bit
+// offsets from the record's own origin in units of 2^e per axis, rounded outward (Ylitie, Karras, Laine: "Efficient
+// Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017).  exps = biased float exponents of the three
+// units, one per byte; byte k of qlo[a] / qhi[a] belongs to child k.  A child that is flat along an axis, which the
+// strict slab test never enters, is stored as kWideEmpty.
+struct alignas(16) DNodeWideQ { float org[3]; uint32_t exps; uint32_t qlo[3], qhi[3]; int32_t child[4]; uint32_t pad[2]; };
+#ifndef RTX_WIDE_QUANT
+#define RTX_WIDE_QUANT 1
+#endif
 // Levels of a four-wide walk's stack kept in LDS; deeper levels (rare) spill to global memory.
 constexpr int kWalkLdsLevels = 12;
 // Shading record of one primitive of a flat scene, in the order the flat intersection tests them (spheres in the
@@ -70,7 +79,8 @@ template <class R> struct DScene {
   const DImage* images; const int32_t* emissive;   // indices of emissive spheres, ascending
   const DNode2<R>* nodes; const DPrimRef* prims;    // production BVH + primitive order (reference leaf order)
   const DNodePair* pairs; const DLeafPrim* leaf_prims; // single-precision traversal layout (NULL in the double scene)
-  const DNodeWide* wide;
+  const DNodeWide* wide;                               // one of the two four-wide forms is built (RTX_WIDE_QUANT)
+  const DNodeWideQ* wideq;
   const DFlatRec* flat;                                // flat scenes only (single precision)
   int32_t n_spheres, n_planes, n_tris, n_boxes, n_points, n_quads, n_disks, n_mats, n_images, n_emissive;
   int32_t n_nodes, n_prims, n_pairs, n_wide;
