@@ -589,6 +589,8 @@ struct MtSampler {
   double light_v() { return next(); }
   double fresnel() { return next(); }
   double roulette() { return next(); }
+  double scatter_u1() { return next(); }
+  double scatter_u2() { return next(); }
   // the two uniforms MNEE::evaluate draws for its j-th light, in order (mnee.hpp:645, :678, :718-720)
   void mnee_pair(int, double& a, double& b) { a = next(); b = next(); }
   V3 unit_vector() {  // random_in_unit_sphere + normalize, renderer.cpp:45-56
@@ -640,6 +642,8 @@ struct CounterSampler {
   double light_select() { return hi(W()[2]); }
   double roulette() { return lo(W()[2]); }
   double fresnel() { return hi(W()[3]); }
+  double scatter_u1() { return hi(W()[1]); }
+  double scatter_u2() { return lo(W()[1]); }
   // MNEE light j of this vertex: extra block (1 + bounce) | ((1 + j / 4) << 16), word j % 4, high | low field
   void mnee_pair(int j, double& a, double& b) {
     uint32_t o[4];
@@ -1250,6 +1254,332 @@ V3 whitted_radiance(const orc_scene& s, const rtx_settings& st, Ray r, int depth
   return background(s, st, r);
 }
 
+
+// ----------------------------------------------------------------------------------------
+// BDPTIntegrator — engine/bdpt.cpp.  Sampler B numbers the blocks of the light subpath from 0x8001 (its origin) on;
+// a vertex of either subpath draws from the fields of its own block: word0 = cosine-hemisphere r1 | r2 of the light's
+// emission direction, word1 = scatter r1 | r2 (or the unit vector, or the point on a quad / disk light),
+// word2 = light choice | roulette, word3 = fresnel.
+// ----------------------------------------------------------------------------------------
+constexpr double kBdptEps = 1e-6;          // bdpt.cpp:14
+constexpr double kInvPi = 0.31830988618379067;   // material.hpp:24
+
+struct BVertex {                            // PathVertex, bdpt.hpp:54-110 (the members the integrator reads)
+  int type = 2;                             // 0 camera, 1 light, 2 surface
+  V3 p{0, 0, 0}, n{0, 1, 0};
+  int mat_type = RTX_MAT_LAMBERTIAN;
+  V3 albedo{1, 1, 1};
+  double roughness = 0.0, ior = 1.5;
+  V3 thr{1, 1, 1};
+  double pdf_fwd = 0.0;
+  V3 Le{0, 0, 0};
+  V3 wi{0, 0, 0}, wo{0, 0, 0};
+  bool connectible() const {               // bdpt.hpp:88-101
+    if (type == 1 || type == 0) return true;
+    return !(mat_type == RTX_MAT_METAL && roughness < 0.001) && mat_type != RTX_MAT_DIELECTRIC;
+  }
+  bool is_light() const { return type == 1 || len2(Le) > 0.001; }   // bdpt.hpp:106-109
+};
+
+inline V3 bdpt_cosine_hemisphere(V3 normal, double r1, double r2) {   // bdpt.cpp:39-65
+  double phi = 2.0 * kPi * r1;
+  double cos_theta = std::sqrt(r2), sin_theta = std::sqrt(1.0 - r2);
+  double x = std::cos(phi) * sin_theta, y = std::sin(phi) * sin_theta, z = cos_theta;
+  V3 w = normal;
+  V3 a = (std::fabs(w.x) > 0.9) ? V3{0, 1, 0} : V3{1, 0, 0};
+  V3 u = normalize(cross(a, w));
+  V3 v = cross(w, u);
+  return normalize(V3{u.x * x + v.x * y + w.x * z, u.y * x + v.y * y + w.y * z, u.z * x + v.z * y + w.z * z});
+}
+
+inline V3 bdpt_eval_bsdf(const BVertex& v, V3 wi, V3 wo) {   // bdpt.cpp:489-527
+  double cos_o = dot(v.n, wo);
+  if (v.mat_type == RTX_MAT_LAMBERTIAN) {
+    if (cos_o <= 0) return {0, 0, 0};
+    return scale(v.albedo, kInvPi);
+  }
+  if (v.mat_type == RTX_MAT_METAL) {
+    if (cos_o <= 0) return {0, 0, 0};
+    V3 reflected = reflect(neg(wi), v.n);
+    double cos_r = dot(reflected, wo);
+    if (v.roughness < 0.001) return {0, 0, 0};
+    double n = 2.0 / (v.roughness * v.roughness) - 2.0;
+    if (cos_r > 0) { double D = (n + 1.0) * kInvPi * 0.5 * std::pow(cos_r, n); return scale(v.albedo, D); }
+    return {0, 0, 0};
+  }
+  return {0, 0, 0};
+}
+
+inline double bdpt_bsdf_pdf(const BVertex& v, V3 wi, V3 wo) {   // bdpt.cpp:529-560
+  double cos_o = dot(v.n, wo);
+  if (v.mat_type == RTX_MAT_LAMBERTIAN) { if (cos_o <= 0) return 0; return cos_o * kInvPi; }
+  if (v.mat_type == RTX_MAT_METAL) {
+    if (cos_o <= 0) return 0;
+    if (v.roughness < 0.001) return 0;
+    V3 reflected = reflect(neg(wi), v.n);
+    double cos_r = dot(reflected, wo);
+    if (cos_r > 0) { double n = 2.0 / (v.roughness * v.roughness) - 2.0; return (n + 1.0) * kInvPi * 0.5 * std::pow(cos_r, n); }
+    return 0;
+  }
+  return 0;
+}
+
+template <class S> bool bdpt_sample_bsdf(const BVertex& v, V3 wi, V3& wo, double& pdf, V3& f, S& rng) {   // bdpt.cpp:562-631
+  if (v.mat_type == RTX_MAT_LAMBERTIAN) {
+    double r1 = rng.scatter_u1(), r2 = rng.scatter_u2();
+    wo = bdpt_cosine_hemisphere(v.n, r1, r2);
+    pdf = dot(v.n, wo) * kInvPi;
+    f = scale(v.albedo, kInvPi);
+    return true;
+  }
+  if (v.mat_type == RTX_MAT_METAL) {
+    V3 reflected = reflect(neg(wi), v.n);
+    if (v.roughness < 0.001) { wo = reflected; pdf = 1.0; f = v.albedo; return true; }
+    V3 jit = scale(rng.unit_vector(), v.roughness);
+    wo = normalize(add(reflected, jit));
+    if (dot(wo, v.n) <= 0) return false;
+    double cos_r = dot(reflected, wo);
+    double n = 2.0 / (v.roughness * v.roughness) - 2.0;
+    pdf = (n + 1.0) * kInvPi * 0.5 * std::pow(std::max(0.0, cos_r), n);
+    f = v.albedo;
+    return true;
+  }
+  if (v.mat_type == RTX_MAT_DIELECTRIC) {
+    double cos_i = dot(wi, v.n);
+    double eta = (cos_i > 0) ? (1.0 / v.ior) : v.ior;
+    V3 n = (cos_i > 0) ? v.n : neg(v.n);
+    cos_i = std::fabs(cos_i);
+    double sin2 = eta * eta * (1.0 - cos_i * cos_i);
+    double r0 = (1.0 - v.ior) / (1.0 + v.ior);
+    r0 = r0 * r0;
+    double fresnel = r0 + (1.0 - r0) * std::pow(1.0 - cos_i, 5.0);
+    if (sin2 > 1.0 || rng.fresnel() < fresnel) wo = reflect(neg(wi), n);   // the uniform is drawn only when refraction is possible
+    else wo = refract(neg(wi), n, eta);
+    pdf = 1.0; f = {1, 1, 1};
+    return true;
+  }
+  return false;
+}
+
+// the loop shared by trace_eye_path (bdpt.cpp:145-217) and trace_light_path (:248-306); eye = area-light hits end the
+// path WITH a light vertex, surface vertices carry the material's emission
+template <class S> void bdpt_walk(const orc_scene& s, const rtx_settings& st, Ray ray, V3 thr, bool eye, int level0, std::vector<BVertex>& path, S& rng, Tally& tl) {
+  for (int bounce = 0; bounce < st.max_depth; ++bounce) {
+    rng.begin_bounce(level0 + bounce);
+    Hit rec;
+    tl.closest++;
+    if (!scene_hit(s, ray, 0.001, 1e9, rec)) break;
+    if (rec.mat < 0) {
+      if (eye) {
+        tl.segments++;
+        BVertex lv;
+        lv.type = 1; lv.p = rec.p; lv.n = rec.n; lv.Le = area_light_emission(s, rec.mat); lv.thr = thr;
+        lv.wi = neg(normalize(ray.d));
+        path.push_back(lv);
+      }
+      break;
+    }
+    tl.segments++;
+    const rtx_material& m = s.mats[rec.mat];
+    BVertex v;
+    v.type = 2; v.p = rec.p; v.n = rec.n; v.mat_type = m.type;
+    v.albedo = albedo_at(s, m, rec.p, rec.u, rec.v);
+    if (eye) v.Le = mk(m.emission);
+    v.roughness = m.fuzz; v.ior = m.refraction_index;
+    v.thr = thr;
+    v.wi = neg(normalize(ray.d));
+    path.push_back(v);
+    V3 wo, f;
+    double pdf;
+    if (!bdpt_sample_bsdf(v, v.wi, wo, pdf, f, rng)) break;
+    if (pdf < kBdptEps) break;
+    double cos_theta = std::fabs(dot(v.n, wo));
+    thr = mul(thr, scale(f, cos_theta / pdf));
+    if (bounce > 3) {
+      double q = std::max(0.05, 1.0 - std::max({thr.x, thr.y, thr.z}));
+      if (rng.roulette() < q) break;
+      thr = scale(thr, 1.0 / (1.0 - q));
+    }
+    path.back().wo = wo;
+    path.back().pdf_fwd = pdf;
+    ray = Ray{rec.p, wo};
+  }
+}
+
+template <class S> bool bdpt_light_origin(const orc_scene& s, BVertex& v, V3& dir, double& pdf_pos, double& pdf_dir, S& rng) {   // bdpt.cpp:311-413
+  size_t n_point = s.points.size(), n_sph = 0;
+  for (const rtx_sphere& sp : s.spheres) if (len2(mk(s.mats[sp.material_id].emission)) > 0.001) n_sph++;
+  size_t n_quad = s.quads.size(), n_disk = s.disks.size();
+  size_t total = n_point + n_sph + n_quad + n_disk;
+  if (total == 0) return false;
+  double choice_pdf = 1.0 / total;
+  size_t idx = (size_t)(rng.light_select() * total);
+  idx = std::min(idx, total - 1);
+  v.type = 1;
+  if (idx < n_point) {
+    const rtx_point_light& l = s.points[idx];
+    v.p = mk(l.position); v.n = {0, 1, 0}; v.Le = mk(l.intensity);
+    pdf_pos = choice_pdf;
+    dir = rng.unit_vector();
+    pdf_dir = 1.0 / (4.0 * kPi);
+    return true;
+  }
+  idx -= n_point;
+  if (idx < n_sph) {
+    size_t k = 0;
+    for (const rtx_sphere& sp : s.spheres) {
+      const rtx_material& m = s.mats[sp.material_id];
+      if (len2(mk(m.emission)) > 0.001) {
+        if (k == idx) {
+          V3 d = rng.unit_vector();
+          v.p = add(mk(sp.center), scale(d, sp.radius)); v.n = d; v.Le = mk(m.emission);
+          double area = 4.0 * kPi * sp.radius * sp.radius;
+          pdf_pos = choice_pdf / area;
+          double r1 = rng.light_u(), r2 = rng.light_v();
+          dir = bdpt_cosine_hemisphere(d, r1, r2);
+          pdf_dir = dot(d, dir) * kInvPi;
+          return true;
+        }
+        k++;
+      }
+    }
+  }
+  idx -= n_sph;
+  if (idx < n_quad) {
+    const rtx_quad_light& q = s.quads[idx];
+    double u = rng.scatter_u1(), w = rng.scatter_u2();
+    v.p = add(mk(q.corner), add(scale(mk(q.edge_u), u), scale(mk(q.edge_v), w)));   // QuadLight::sample_point, primitives.hpp:258-262
+    v.n = mk(q.normal); v.Le = mk(q.emission);
+    pdf_pos = choice_pdf * (1.0 / q.area);
+    double r1 = rng.light_u(), r2 = rng.light_v();
+    dir = bdpt_cosine_hemisphere(v.n, r1, r2);
+    pdf_dir = dot(v.n, dir) * kInvPi;
+    return true;
+  }
+  idx -= n_quad;
+  if (idx < n_disk) {
+    const rtx_disk_light& dl = s.disks[idx];
+    double u = rng.scatter_u1(), w = rng.scatter_u2();
+    v.p = disk_sample_point(dl, u, w);
+    v.n = mk(dl.normal); v.Le = mk(dl.emission);
+    pdf_pos = choice_pdf * (1.0 / dl.area);
+    double r1 = rng.light_u(), r2 = rng.light_v();
+    dir = bdpt_cosine_hemisphere(v.n, r1, r2);
+    pdf_dir = dot(v.n, dir) * kInvPi;
+    return true;
+  }
+  return false;
+}
+
+inline double bdpt_mis_weight(const std::vector<BVertex>& eye, const std::vector<BVertex>& light, int s_, int t) {   // bdpt.cpp:633-711
+  if (s_ == 0 && t == 1) return 1.0;
+  const BVertex* ev = (t > 0 && t <= (int)eye.size()) ? &eye[t - 1] : nullptr;
+  const BVertex* lv = (s_ > 0 && s_ <= (int)light.size()) ? &light[s_ - 1] : nullptr;
+  double sum_ri = 1.0;
+  double ri = 1.0;
+  if (t > 1 && ev && ev->connectible()) {
+    double pf = ev->pdf_fwd, pr = bdpt_bsdf_pdf(*ev, ev->wo, ev->wi);
+    if (pf > kBdptEps && pr > kBdptEps) { ri *= pr / pf; double ri2 = ri * ri; sum_ri += ri2; }
+  }
+  ri = 1.0;
+  if (s_ > 0 && lv && lv->connectible()) {
+    double pf = lv->pdf_fwd, pr = bdpt_bsdf_pdf(*lv, lv->wo, lv->wi);
+    if (pf > kBdptEps && pr > kBdptEps) { ri *= pr / pf; double ri2 = ri * ri; sum_ri += ri2; }
+  }
+  if (s_ == 0 && ev && ev->is_light()) sum_ri += 1.0;
+  if (s_ == 1 && lv) sum_ri += 0.5;
+  return 1.0 / sum_ri;
+}
+
+inline V3 bdpt_connect(const orc_scene& s, const std::vector<BVertex>& eye, const std::vector<BVertex>& light, int s_, int t, Tally& tl) {   // bdpt.cpp:415-487
+  V3 L = {0, 0, 0};
+  if (t == 0) return L;
+  if (s_ == 0) {
+    const BVertex& ev = eye[t - 1];
+    if (ev.is_light()) L = mul(ev.thr, ev.Le);
+    return L;
+  }
+  if (t == 1) return L;
+  const BVertex& ev = eye[t - 1];
+  const BVertex& lv = light[s_ - 1];
+  {  // visible(), bdpt.cpp:713-723
+    V3 d = sub(lv.p, ev.p);
+    double dist = len(d);
+    if (!(dist < kBdptEps)) {
+      Hit rec;
+      tl.shadow++;
+      if (scene_hit(s, Ray{ev.p, scale(d, 1.0 / dist)}, 0.001, dist - 0.001, rec)) return L;
+    }
+  }
+  V3 d = sub(lv.p, ev.p);
+  double dist_sq = len2(d);
+  double dist = std::sqrt(dist_sq);
+  V3 wo_eye = scale(d, 1.0 / dist);
+  V3 wi_light = neg(wo_eye);
+  V3 f_eye = bdpt_eval_bsdf(ev, ev.wi, wo_eye);
+  if (len2(f_eye) < kBdptEps) return L;
+  V3 f_light;
+  if (s_ == 1) f_light = scale(lv.Le, std::fabs(dot(lv.n, wi_light)));
+  else f_light = bdpt_eval_bsdf(lv, lv.wi, wi_light);
+  if (len2(f_light) < kBdptEps) return L;
+  double G = 0.0;   // geometry_term, bdpt.cpp:725-738
+  {
+    V3 dd = sub(lv.p, ev.p);
+    double d2 = len2(dd);
+    if (!(d2 < kBdptEps)) {
+      double dl = std::sqrt(d2);
+      V3 dir = scale(dd, 1.0 / dl);
+      G = std::fabs(dot(ev.n, dir)) * std::fabs(dot(lv.n, neg(dir))) / d2;
+    }
+  }
+  V3 eye_c = mul(ev.thr, f_eye);
+  V3 light_c = (s_ == 1) ? f_light : mul(lv.thr, f_light);
+  return scale(mul(eye_c, light_c), G);
+}
+
+template <class S>
+V3 bdpt_radiance(const orc_scene& s, const rtx_settings& st, Ray r, S& rng, Tally& tl) {   // BDPTIntegrator::Li, bdpt.cpp:71-128
+  std::vector<BVertex> eye, light;
+  {  // trace_eye_path, bdpt.cpp:130-220
+    BVertex cam;
+    cam.type = 0; cam.p = r.o; cam.thr = {1, 1, 1}; cam.pdf_fwd = 1.0;
+    eye.push_back(cam);
+    bdpt_walk(s, st, r, V3{1, 1, 1}, true, 0, eye, rng, tl);
+  }
+  {  // trace_light_path, bdpt.cpp:222-309
+    rng.begin_bounce(0x8000);
+    BVertex lv;
+    V3 dir;
+    double pdf_pos, pdf_dir;
+    if (bdpt_light_origin(s, lv, dir, pdf_pos, pdf_dir, rng)) {
+      lv.pdf_fwd = pdf_pos;
+      light.push_back(lv);
+      if (!(pdf_dir < kBdptEps)) {
+        double cos_theta = std::fabs(dot(lv.n, dir));
+        V3 thr = scale(lv.Le, cos_theta / (pdf_pos * pdf_dir));
+        bdpt_walk(s, st, Ray{lv.p, dir}, thr, false, 0x8001, light, rng, tl);
+      }
+    }
+  }
+  const int num_eye = (int)eye.size(), num_light = (int)light.size();
+  V3 L = {0, 0, 0};
+  for (int t = 1; t <= num_eye; ++t)
+    for (int s_ = 0; s_ <= num_light; ++s_) {
+      if (s_ + t < 2) continue;
+      if (t > 1 && !eye[t - 1].connectible()) continue;
+      if (s_ > 0 && !light[s_ - 1].connectible()) continue;
+      V3 Lp = bdpt_connect(s, eye, light, s_, t, tl);
+      double w = st.use_mis ? bdpt_mis_weight(eye, light, s_, t) : 1.0;
+      V3 wl = scale(Lp, w);
+      if (st.clamp_max > 0.0) {
+        double lum = 0.2126 * wl.x + 0.7152 * wl.y + 0.0722 * wl.z;
+        if (lum > st.clamp_max) wl = scale(wl, st.clamp_max / lum);
+      }
+      L = add(L, wl);
+    }
+  return L;
+}
+
 inline Ray camera_ray(const rtx_camera& c, double s, double t) {  // scene.hpp:99-108
   V3 o = mk(c.origin);
   V3 d = sub(add(add(mk(c.lower_left_corner), scale(mk(c.horizontal), s)), scale(mk(c.vertical), t)), o);
@@ -1265,7 +1595,7 @@ void render_rows(const orc_scene& s, const rtx_camera& cam, const rtx_settings& 
       double u = ((double)x + rng.jitter_x()) / st.width;
       double v = ((double)y + rng.jitter_y()) / st.height;
       Ray r = camera_ray(cam, u, v);
-      px = add(px, st.mode == RTX_MODE_WHITTED ? whitted_radiance(s, st, r, st.max_depth, 0, rng, tl) : path_radiance(s, st, r, rng, tl));
+      px = add(px, st.mode == RTX_MODE_WHITTED ? whitted_radiance(s, st, r, st.max_depth, 0, rng, tl) : st.mode == RTX_MODE_BDPT ? bdpt_radiance(s, st, r, rng, tl) : path_radiance(s, st, r, rng, tl));
     }
     px = scale(px, 1.0 / st.samples_per_pixel);
     double* o = film + ((size_t)y * st.width + x) * 3;

@@ -270,7 +270,7 @@ int cmd_render(int argc, char** argv) {
   auto d = SceneLoader::load(scene_path);
   Renderer::Settings st;
   st.width = W; st.height = H; st.samples_per_pixel = spp; st.max_depth = depth;
-  st.mode = (argc > 13 && atoi(argv[13]) == 0) ? RenderMode::Whitted : RenderMode::PathTrace;   // optional 12th value: RenderMode
+  st.mode = (argc > 13 && atoi(argv[13]) == 0) ? RenderMode::Whitted : (argc > 13 && atoi(argv[13]) == 2) ? RenderMode::BDPT : RenderMode::PathTrace;   // optional 12th value: RenderMode
   st.use_nee = nee; st.use_mis = mis; st.use_mnee = mnee;
   st.tone_mapper = ToneMapper::None;
   // ToneMapper::None still clamps to [0,1] (engine/renderer.cpp:175-182).  Scaling by an

@@ -232,6 +232,7 @@ class SceneData:
         st.precision = abi.PRECISION_F32
         st.pipeline = abi.PIPELINE_AUTO
         st.shard_index, st.shard_count = 0, 1
+        st.clamp_max = self.clamp_max
         st.mode = abi.MODE_PATHTRACE   # the hot path; pass mode=self.mode (or abi.MODE_WHITTED) for the scene file's own mode
         for k, v in over.items():
             if not hasattr(st, k):

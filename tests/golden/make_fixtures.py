@@ -222,6 +222,19 @@ def make_normal_map_fixtures():
         print("film", tag, float(film.mean()))
 
 
+# RenderMode::BDPT (BDPTIntegrator::Li, engine/bdpt.cpp): every light type, rough / mirror metals, glass, textures
+BDPT_FILMS = [("caustics_test", 24, 24, 4, 16, 121, 1), ("cornell_box", 24, 14, 4, 8, 122, 1), ("cornell_box", 24, 14, 3, 8, 123, 0), ("cornell_box_quad", 20, 20, 4, 12, 124, 1),
+              ("kitchen_sink", 32, 18, 4, 10, 125, 1), ("disk_room", 24, 14, 4, 8, 126, 1), ("textured", 24, 14, 3, 6, 127, 1), ("kitchen_points", 24, 14, 3, 6, 128, 1)]
+
+
+def make_bdpt_fixtures():
+    for (n, W, H, spp, depth, seed, mis) in BDPT_FILMS:
+        film, _ = ref_film(n, W, H, spp, depth, seed, 1, mis, mode=2)
+        tag = f"{n}_{W}x{H}_s{spp}_d{depth}_seed{seed}_mis{mis}_bdpt"
+        np.savez_compressed(os.path.join(HERE, "films", tag + ".npz"), film=film, scene=n, W=W, H=H, spp=spp, depth=depth, seed=seed, nee=1, mis=mis, mode=2)
+        print("film", tag, float(film.mean()))
+
+
 def rel_mse(x, r):
     x = np.clip(x, 0.0, 1.0); r = np.clip(r, 0.0, 1.0)   # the film Renderer::render returns is clamped
     return float(np.mean((x - r) ** 2 / (r ** 2 + 1e-2)))
@@ -237,6 +250,9 @@ def main():
         return
     if "--whitted-only" in sys.argv:
         make_whitted_fixtures()
+        return
+    if "--bdpt-only" in sys.argv:
+        make_bdpt_fixtures()
         return
     if "--normal-only" in sys.argv:
         make_normal_map_fixtures()
@@ -287,6 +303,7 @@ def main():
     make_mnee_fixtures()
     make_whitted_fixtures()
     make_normal_map_fixtures()
+    make_bdpt_fixtures()
 
     # --- converged references + noise floor ----------------------------------------------
     for n, depth in (("cornell_box", 500), ("cornell_box_quad", 50), ("caustics_test", 16), ("environment_demo", 50), ("kitchen_sink", 24)):
