@@ -1,5 +1,6 @@
 // Single-precision instantiations: the production kernels.
 #include "pt_kernels.hpp"
+#include "pt_bdpt.hpp"
 #include "pt_host.hpp"
 
 namespace rtx {
@@ -12,6 +13,16 @@ __global__ void selftest_kernel(float* out, int n) {
 
 void launch_selftest(float* out, int n, hipStream_t stream) {
   hipLaunchKernelGGL(selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n);
+}
+
+int launch_render_bdpt(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters, const FusedLaunch& L,
+                       float* light_store, unsigned long long store_cap, hipStream_t stream) {
+  dim3 g(L.grid), b(kBlock);
+  if (L.mode == MODE_FLAT && L.lds_mats) { hipLaunchKernelGGL((render_bdpt_kernel<float, MODE_FLAT, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int, light_store, store_cap); return 0; }
+  if (L.mode == MODE_FLAT) return -1;
+  if (L.lds_mats) hipLaunchKernelGGL((render_bdpt_kernel<float, MODE_TREE_UV, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int, light_store, store_cap);
+  else hipLaunchKernelGGL((render_bdpt_kernel<float, MODE_TREE_UV, false>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int, light_store, store_cap);
+  return 0;
 }
 
 int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,

@@ -2,6 +2,7 @@
 // Built with -ffp-contract=off so that no multiply-add is fused: the reference CPU build
 // (baseline x86-64) rounds after every multiply and every add, and so must these.
 #include "pt_kernels.hpp"
+#include "pt_bdpt.hpp"
 #include "pt_host.hpp"
 
 namespace rtx {
@@ -58,6 +59,15 @@ void launch_trace_ref(const DScene<double>& sc, const DSceneRef& ref, const doub
   if (n == 0) return;
   unsigned grid = (unsigned)((n + 63) / 64);
   hipLaunchKernelGGL(trace_ref_kernel, dim3(grid), dim3(64), 0, stream, sc, ref, rays8, n, out);
+}
+
+int launch_render_bdpt(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters, const FusedLaunch& L,
+                       double* light_store, unsigned long long store_cap, hipStream_t stream) {
+  dim3 g(L.grid), b(kBlock);
+  if (L.mode == MODE_FLAT) return -1;
+  if (L.lds_mats) hipLaunchKernelGGL((render_bdpt_kernel<double, MODE_TREE_UV, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int, light_store, store_cap);
+  else hipLaunchKernelGGL((render_bdpt_kernel<double, MODE_TREE_UV, false>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int, light_store, store_cap);
+  return 0;
 }
 
 int launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters,

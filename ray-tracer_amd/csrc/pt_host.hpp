@@ -68,6 +68,11 @@ struct FusedLaunch {
   int stack_first_int;  // offset (in ints) of the traversal stacks inside the dynamic LDS
   int integ = INTEG_PATH;  // INTEG_*: path tracing, path tracing with MNEE (double precision only), Whitted (TREE_UV instances only)
 };
+// BDPT (pt_bdpt.hpp): `light_store` holds kBdptFields * store_cap values per lane of the grid (store_cap = max_depth + 1 kept light vertices)
+int launch_render_bdpt(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters, const FusedLaunch& L,
+                       float* light_store, unsigned long long store_cap, hipStream_t stream);
+int launch_render_bdpt(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters, const FusedLaunch& L,
+                       double* light_store, unsigned long long store_cap, hipStream_t stream);
 int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
                         const FusedLaunch& L, hipStream_t stream);
 int launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters,

@@ -101,6 +101,7 @@ struct DRenderParams {
   uint32_t seed;
   int32_t rng;                              // RNG_PHILOX / RNG_PCG4D (pt_device.hpp)
   double bg[3], bg_top[3], bg_bottom[3];
+  double clamp_max;                         // BDPT: luminance cap per strategy, <= 0 off
 };
 
 struct DCounters { unsigned long long samples, closest, shadow, segments; };
@@ -118,7 +119,8 @@ constexpr int kStackDepth = 48;      // per-lane traversal stack entries (LDS)
 // How a kernel instance intersects (see pt_device.hpp).
 enum { MODE_TREE = 0, MODE_TREE_UV = 1, MODE_FLAT = 2 };
 // Integrator a fused kernel instance runs: ray_color_path, ray_color_path with MNEE, ray_color_whitted.
-enum { INTEG_PATH = 0, INTEG_PATH_MNEE = 1, INTEG_WHITTED = 2 };
+enum { INTEG_PATH = 0, INTEG_PATH_MNEE = 1, INTEG_WHITTED = 2, INTEG_BDPT = 3 };
+constexpr int kBdptStoreFields = 18;   // values kept per connectible light-subpath vertex (pt_bdpt.hpp)
 constexpr int kFlatMaxSpheres = 16;   // flat mode: sphere-only bounded primitives, at most this many
 constexpr size_t kMaxLdsMaterialBytes = 32768;
 

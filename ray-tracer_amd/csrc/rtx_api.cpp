@@ -49,7 +49,7 @@ struct rtx_ctx {
   HostScene scene;          // device-resident copies + BVHs
   DCamera<float> cam_f;
   DCamera<double> cam_d;
-  DeviceBuffer partial, film, counters, rays, hits, post_in, post_out;
+  DeviceBuffer partial, film, counters, rays, hits, post_in, post_out, bdpt_store;
   WavefrontPool wf;         // wavefront-pipeline queues, allocated on first use
 };
 
@@ -104,7 +104,7 @@ int rtx_destroy(rtx_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   c->scene.release();
-  c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release(); c->post_in.release(); c->post_out.release();
+  c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release(); c->post_in.release(); c->post_out.release(); c->bdpt_store.release();
   c->wf.release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -156,7 +156,9 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   if (s->shard_index < 0 || s->shard_index >= sc_n) return fail(RTX_ERR_INVALID_ARGUMENT, "shard %d of %d", s->shard_index, sc_n);
   if (s->precision != RTX_PRECISION_F32 && s->precision != RTX_PRECISION_F64) return fail(RTX_ERR_INVALID_ARGUMENT, "precision %d", s->precision);
   if (s->pipeline < RTX_PIPELINE_AUTO || s->pipeline > RTX_PIPELINE_WAVEFRONT) return fail(RTX_ERR_INVALID_ARGUMENT, "pipeline %d", s->pipeline);
-  if (s->mode != RTX_MODE_WHITTED && s->mode != RTX_MODE_PATHTRACE) return fail(RTX_ERR_UNSUPPORTED, "render mode %d: only Whitted (0) and PathTrace (1) are implemented", s->mode);
+  if (s->mode != RTX_MODE_WHITTED && s->mode != RTX_MODE_PATHTRACE && s->mode != RTX_MODE_BDPT)
+    return fail(RTX_ERR_UNSUPPORTED, "render mode %d: only Whitted (0), PathTrace (1) and BDPT (2) are implemented", s->mode);
+  if (s->mode == RTX_MODE_BDPT && !(s->clamp_max == s->clamp_max)) return fail(RTX_ERR_INVALID_ARGUMENT, "clamp_max is NaN");
   if (s->rng < RTX_RNG_AUTO || s->rng > RTX_RNG_PCG4D) return fail(RTX_ERR_INVALID_ARGUMENT, "rng %d", s->rng);
   if (!host_out && !dev_out) return fail(RTX_ERR_INVALID_ARGUMENT, "output buffer is NULL");
   HIP_TRY(hipSetDevice(c->device));
@@ -175,6 +177,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   P.chunk_spp = (P.spp + target_chunks - 1) / target_chunks;
   P.n_chunks = (P.spp + P.chunk_spp - 1) / P.chunk_spp;
   P.seed = s->seed;
+  P.clamp_max = s->clamp_max;
   P.rng = (s->rng == RTX_RNG_PCG4D || (s->rng == RTX_RNG_AUTO && s->precision == RTX_PRECISION_F32 && !(s->use_mnee && s->use_nee && s->mode == RTX_MODE_PATHTRACE))) ? 1 /* RNG_PCG4D */ : 0;
   for (int i = 0; i < 3; ++i) { P.bg[i] = s->background_color[i]; P.bg_top[i] = s->background_top[i]; P.bg_bottom[i] = s->background_bottom[i]; }
 
@@ -185,14 +188,16 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   // Manifold next event estimation runs in the double-precision fused kernel only (its Newton solver's
   // tolerances leave no room for single precision): a single-precision request is promoted.
   const bool whitted = s->mode == RTX_MODE_WHITTED;
-  const bool mnee = !whitted && s->use_mnee != 0 && s->use_nee != 0;
+  const bool bdpt = s->mode == RTX_MODE_BDPT;
+  const bool mnee = !whitted && !bdpt && s->use_mnee != 0 && s->use_nee != 0;
   const bool f64 = s->precision == RTX_PRECISION_F64 || mnee;
   const bool f64_req = f64;
   // AUTO: scenes that walk a tree run the queue-based pipeline (its traversal kernels hold 2-4x
   // the waves of the fused kernel, measured 1.6x faster on a 10 M-triangle scene); scenes small
   // enough for the linear / flat intersection stay fused (no queue traffic, measured 2-3x faster).
   int pipeline = s->pipeline;
-  if (pipeline == RTX_PIPELINE_AUTO) pipeline = (!f64_req && !whitted && c->scene.n_prims > kLinearMaxPrims) ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED;
+  if (pipeline == RTX_PIPELINE_AUTO) pipeline = (!f64_req && !whitted && !bdpt && c->scene.n_prims > kLinearMaxPrims) ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED;
+  if (pipeline == RTX_PIPELINE_WAVEFRONT && bdpt) return fail(RTX_ERR_UNSUPPORTED, "the BDPT mode is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && whitted) return fail(RTX_ERR_UNSUPPORTED, "the Whitted mode is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && mnee) return fail(RTX_ERR_UNSUPPORTED, "use_mnee is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && f64) return fail(RTX_ERR_UNSUPPORTED, "the wavefront pipeline is single precision only");
@@ -214,7 +219,8 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     if (!c->partial.ensure((size_t)items * 3 * elem)) return fail(RTX_ERR_OUT_OF_MEMORY, "chunk-sum buffer (%llu bytes)", (unsigned long long)(items * 3 * elem));
     FusedLaunch L;
     L.mode = whitted ? MODE_TREE_UV : c->scene.fused_mode(f64);
-    L.integ = whitted ? INTEG_WHITTED : mnee ? INTEG_PATH_MNEE : INTEG_PATH;
+    if (bdpt && L.mode == MODE_TREE) L.mode = MODE_TREE_UV;
+    L.integ = whitted ? INTEG_WHITTED : bdpt ? INTEG_BDPT : mnee ? INTEG_PATH_MNEE : INTEG_PATH;
     const size_t mat_bytes = (size_t)c->scene.dev_f.n_mats * (f64 ? sizeof(DMaterial<double>) : sizeof(DMaterial<float>));
     L.lds_mats = mat_bytes <= kMaxLdsMaterialBytes;
     if (!L.lds_mats) L.mode = MODE_TREE_UV;
@@ -225,7 +231,20 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     const int blocks_per_cu = stack ? 3 : 6;
     L.grid = (int)std::min<unsigned long long>((items + kBlock - 1) / kBlock, (unsigned long long)c->n_cus * blocks_per_cu);
     int lrc;
-    if (f64) {
+    if (bdpt) {
+      // every lane keeps the connectible vertices of its light subpath (at most max_depth + 1) in global memory;
+      // the grid shrinks when that would pass 2 GiB
+      const unsigned long long cap = (unsigned long long)P.max_depth + 1ull;
+      const unsigned long long per_lane = (unsigned long long)kBdptStoreFields * cap * elem;
+      const unsigned long long max_lanes = std::max<unsigned long long>(kBlock, (2ull << 30) / per_lane / kBlock * kBlock);
+      if ((unsigned long long)L.grid * kBlock > max_lanes) L.grid = (int)(max_lanes / kBlock);
+      if (!c->bdpt_store.ensure((size_t)((unsigned long long)L.grid * kBlock * per_lane))) return fail(RTX_ERR_OUT_OF_MEMORY, "BDPT light-vertex store (%llu bytes)", (unsigned long long)L.grid * kBlock * per_lane);
+      if (f64) lrc = launch_render_bdpt(c->scene.dev_d, c->cam_d, P, (double*)c->partial.ptr, (DCounters*)c->counters.ptr, L, (double*)c->bdpt_store.ptr, cap, stream);
+      else lrc = launch_render_bdpt(c->scene.dev_f, c->cam_f, P, (float*)c->partial.ptr, (DCounters*)c->counters.ptr, L, (float*)c->bdpt_store.ptr, cap, stream);
+      HIP_TRY(hipEventRecord(c->evm, stream));
+      if (f64) launch_film_reduce((const double*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
+      else launch_film_reduce((const float*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
+    } else if (f64) {
       lrc = launch_render_fused(c->scene.dev_d, c->cam_d, P, (double*)c->partial.ptr, (DCounters*)c->counters.ptr, L, stream);
       HIP_TRY(hipEventRecord(c->evm, stream));
       launch_film_reduce((const double*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);

@@ -179,6 +179,49 @@ def test_whitted_film_equals_oracle(name, pkg, oracle, tracer, load_scene):
         assert got.mean() > 0.05
 
 
+@pytest.mark.parametrize("name,mis", [("caustics_test", 1), ("cornell_box", 1), ("cornell_box", 0), ("cornell_box_quad", 1), ("kitchen_sink", 1), ("disk_room", 1),
+                                      ("textured", 1), ("kitchen_points", 1), ("soup", 1)])
+def test_bdpt_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
+    """RenderMode::BDPT (BDPTIntegrator::Li, engine/bdpt.cpp:71-128; the native mode of caustics_test.json): double precision
+    agrees with the oracle on the same counter-based numbers (the oracle equals the real reference bit for bit on 8 seeded
+    films, test_seeded_film_bit_exact), single precision with the oracle fed by the pcg4d generator to rounding.  All
+    three counters are equal in double precision: the kernel traces the rays the reference traces, in its order."""
+    sd = soup_scene(pkg, load_scene) if name == "soup" else load_scene(name)
+    W, H, spp = 40, 24, 6
+    over = dict(width=W, height=H, samples_per_pixel=spp, max_depth=min(sd.max_depth, 12), seed=71, use_mis=mis, mode=pkg.abi.MODE_BDPT)
+    ref, ost = oracle.OracleScene(sd).render(sd.camera(W, H), sd.settings(**over), oracle.RNG_COUNTER, threads=16)
+    pt = tracer(sd)
+    pt.set_camera(sd.camera(W, H))
+    pt.set_settings(sd.settings(precision=pkg.abi.PRECISION_F64, **over))
+    got = pt.render().astype(np.float64)
+    st = pt.last_stats
+    loose = name in ("kitchen_sink", "kitchen_points")   # checker floor in the plane y = 0 (see test_f64_film_equals_oracle)
+    assert st.samples == W * H * spp and st.pipeline_used == pkg.abi.PIPELINE_FUSED and st.precision_used == pkg.abi.PRECISION_F64
+    if not loose:
+        assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow and st.segments == ost.segments
+    bad = (np.abs(got - ref) > 1e-5 * (1.0 + np.abs(ref))).any(axis=2)
+    assert bad.mean() < (0.03 if loose else 0.005), (bad.mean(), np.abs(got - ref).max())
+    assert abs(got.mean() - ref.mean()) < (3e-3 if loose else 2e-4) * (1 + ref.mean())
+    assert ref.mean() > 1e-3
+    # single precision, pcg4d numbers
+    ref32, _ = oracle.OracleScene(sd).render(sd.camera(W, H), sd.settings(**over), oracle.RNG_COUNTER_PCG, threads=16)
+    pt.set_settings(sd.settings(precision=pkg.abi.PRECISION_F32, **over))
+    f32 = pt.render().astype(np.float64)
+    assert pt.last_stats.precision_used == pkg.abi.PRECISION_F32 and pt.last_stats.samples == W * H * spp
+    if loose:
+        # the checker texture on the plane y = 0 takes floor(y / scale) of a rounding residue, whose sign differs between
+        # the precisions over the whole plane (texture.hpp:276-280): only the image mean is comparable
+        assert abs(f32.mean() - ref32.mean()) < 0.05 * (1 + ref32.mean())
+    else:
+        bad = (np.abs(f32 - ref32) > 2e-3 * (1.0 + np.abs(ref32))).any(axis=2)
+        assert bad.mean() < 0.03, (bad.mean(), np.abs(f32 - ref32).max())
+        assert abs(f32.mean() - ref32.mean()) < 0.02 * (1 + ref32.mean())
+    # the queue pipeline has no BDPT
+    pt.set_settings(sd.settings(pipeline=pkg.abi.PIPELINE_WAVEFRONT, **over))
+    with pytest.raises(pkg.abi.RtxError):
+        pt.render()
+
+
 @pytest.mark.parametrize("name,mis", [("cornell_box", 1), ("cornell_box", 0), ("cornell_box_quad", 1), ("caustics_test", 1), ("kitchen_sink", 0), ("disk_room", 1), ("normal_mapped", 1)])
 def test_mnee_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
     """use_mnee = 1 (the reference's CLI default; MNEE::evaluate, engine/spectral/mnee.hpp:632-763): the render is
