@@ -235,6 +235,19 @@ def make_bdpt_fixtures():
         print("film", tag, float(film.mean()))
 
 
+def make_bdpt_converged():
+    """BDPT films of the real reference at 4N spp plus two N-spp films of other seeds (the Monte-Carlo noise floor)."""
+    for n, depth in (("caustics_test", 16), ("cornell_box_quad", 12)):
+        W, H, N = 64, 36, 256
+        hi, secs = ref_film(n, W, H, 4 * N, depth, 1001, threads=8, mode=2)
+        lo_a, _ = ref_film(n, W, H, N, depth, 2002, threads=8, mode=2)
+        lo_b, _ = ref_film(n, W, H, N, depth, 3003, threads=8, mode=2)
+        floor = max(rel_mse(lo_a, hi), rel_mse(lo_b, hi))
+        np.savez_compressed(os.path.join(HERE, "converged", n + "_bdpt.npz"), film=hi.astype(np.float32), W=W, H=H, N=N, depth=depth, mode=2,
+                            noise_floor_relmse=floor, ref_msamples_per_s_8threads=W * H * 4 * N / secs * 1e-6)
+        print("converged bdpt", n, "floor", floor, "ref Msamples/s", W * H * 4 * N / secs * 1e-6)
+
+
 def rel_mse(x, r):
     x = np.clip(x, 0.0, 1.0); r = np.clip(r, 0.0, 1.0)   # the film Renderer::render returns is clamped
     return float(np.mean((x - r) ** 2 / (r ** 2 + 1e-2)))
@@ -253,6 +266,7 @@ def main():
         return
     if "--bdpt-only" in sys.argv:
         make_bdpt_fixtures()
+        make_bdpt_converged()
         return
     if "--normal-only" in sys.argv:
         make_normal_map_fixtures()
@@ -316,6 +330,8 @@ def main():
                             noise_floor_relmse=floor, mean_lo_a=lo_a.mean(axis=(0, 1)), mean_lo_b=lo_b.mean(axis=(0, 1)),
                             ref_msamples_per_s_8threads=W * H * 4 * N / secs * 1e-6)
         print("converged", n, "floor", floor, "ref Msamples/s", W * H * 4 * N / secs * 1e-6)
+
+    make_bdpt_converged()
 
     # --- scalar known answers ---------------------------------------------------------------
     for n in ("kitchen_sink", "environment_demo", "cornell_box", "textured", "disk_room"):

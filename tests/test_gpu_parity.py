@@ -184,8 +184,9 @@ def test_whitted_film_equals_oracle(name, pkg, oracle, tracer, load_scene):
 def test_bdpt_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
     """RenderMode::BDPT (BDPTIntegrator::Li, engine/bdpt.cpp:71-128; the native mode of caustics_test.json): double precision
     agrees with the oracle on the same counter-based numbers (the oracle equals the real reference bit for bit on 8 seeded
-    films, test_seeded_film_bit_exact), single precision with the oracle fed by the pcg4d generator to rounding.  All
-    three counters are equal in double precision: the kernel traces the rays the reference traces, in its order."""
+    films, test_seeded_film_bit_exact), single precision with the oracle fed by the pcg4d generator to rounding.  The
+    subpaths are the reference's vertex for vertex (equal closest-hit and vertex counters in double precision); visibility
+    rays are fewer, because the kernel casts one only for a connection whose BSDF and geometry terms are not zero."""
     sd = soup_scene(pkg, load_scene) if name == "soup" else load_scene(name)
     W, H, spp = 40, 24, 6
     over = dict(width=W, height=H, samples_per_pixel=spp, max_depth=min(sd.max_depth, 12), seed=71, use_mis=mis, mode=pkg.abi.MODE_BDPT)
@@ -198,7 +199,7 @@ def test_bdpt_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
     loose = name in ("kitchen_sink", "kitchen_points")   # checker floor in the plane y = 0 (see test_f64_film_equals_oracle)
     assert st.samples == W * H * spp and st.pipeline_used == pkg.abi.PIPELINE_FUSED and st.precision_used == pkg.abi.PRECISION_F64
     if not loose:
-        assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow and st.segments == ost.segments
+        assert st.rays_closest == ost.rays_closest and st.segments == ost.segments and 0 < st.rays_shadow <= ost.rays_shadow
     bad = (np.abs(got - ref) > 1e-5 * (1.0 + np.abs(ref))).any(axis=2)
     assert bad.mean() < (0.03 if loose else 0.005), (bad.mean(), np.abs(got - ref).max())
     assert abs(got.mean() - ref.mean()) < (3e-3 if loose else 2e-4) * (1 + ref.mean())
@@ -253,7 +254,7 @@ def test_mnee_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
         assert np.abs(ref - off).max() > 1e-3   # MNEE does contribute in these scenes
 
 
-@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "caustics_test", "environment_demo"])
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "caustics_test", "environment_demo", "caustics_test_bdpt", "cornell_box_quad_bdpt"])
 def test_f32_film_within_tolerance_of_reference(name, pkg, tracer, load_scene):
     """Converged-image criterion: relMSE(GPU @ N spp vs reference @ 4N spp) <= 1.25 x
     relMSE(reference @ N vs reference @ 4N, other seeds), relMSE = mean((x-r)^2 / (r^2 + 0.01)) on
@@ -261,19 +262,20 @@ def test_f32_film_within_tolerance_of_reference(name, pkg, tracer, load_scene):
     seed to seed (scripts/rng_quality.py, 64 seeds, either generator), so it is averaged over four seeds here; the
     means are taken from a 16N-spp film, whose own noise is below the reference film's."""
     fx = np.load(os.path.join(GOLDEN, "converged", name + ".npz"))
-    sd = load_scene(name)
+    sd = load_scene(name[:-5] if name.endswith("_bdpt") else name)   # *_bdpt: the reference's films in RenderMode::BDPT
+    mode = int(fx["mode"]) if "mode" in fx else pkg.abi.MODE_PATHTRACE
     W, H, N = int(fx["W"]), int(fx["H"]), int(fx["N"])
     pt = tracer(sd)
     pt.set_camera(sd.camera(W, H))
     ref = fx["film"].astype(np.float64)
     errs = []
     for seed in (2024, 2026, 2027, 2028):
-        pt.set_settings(sd.settings(width=W, height=H, samples_per_pixel=N, max_depth=int(fx["depth"]), seed=seed))
+        pt.set_settings(sd.settings(width=W, height=H, samples_per_pixel=N, max_depth=int(fx["depth"]), seed=seed, mode=mode))
         errs.append(rel_mse(pt.render().astype(np.float64), ref))
     assert np.mean(errs) <= 1.25 * float(fx["noise_floor_relmse"]), (errs, float(fx["noise_floor_relmse"]))
     assert max(errs) <= 1.8 * float(fx["noise_floor_relmse"]), errs
     # many more samples than the reference: error must drop to the reference film's own noise
-    pt.set_settings(sd.settings(width=W, height=H, samples_per_pixel=16 * N, max_depth=int(fx["depth"]), seed=2025))
+    pt.set_settings(sd.settings(width=W, height=H, samples_per_pixel=16 * N, max_depth=int(fx["depth"]), seed=2025, mode=mode))
     film16 = pt.render().astype(np.float64)
     assert rel_mse(film16, ref) <= 0.6 * float(fx["noise_floor_relmse"])
     mg, mr = np.clip(film16, 0, 1).mean(axis=(0, 1)), np.clip(ref, 0, 1).mean(axis=(0, 1))
