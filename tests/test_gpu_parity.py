@@ -364,7 +364,23 @@ def test_error_paths(pkg, load_scene):
         pt.set_settings(sd.settings(width=8, height=8, samples_per_pixel=1, shard_index=2, shard_count=2))
         with pytest.raises(abi.RtxError, match="shard"):
             pt.render()
+        pt.set_settings(sd.settings(width=8, height=8, samples_per_pixel=1, mode=3))   # RenderMode::Spectral
+        with pytest.raises(abi.RtxError, match="render mode 3"):
+            pt.render()
+        pt.set_settings(sd.settings(width=8, height=8, samples_per_pixel=1, mode=abi.MODE_BDPT, clamp_max=float("nan")))
+        with pytest.raises(abi.RtxError, match="clamp_max"):
+            pt.render()
+        pt.set_settings(sd.settings(width=8, height=8, samples_per_pixel=2, max_depth=0, mode=abi.MODE_BDPT))   # no bounces: black, as in the reference
+        assert float(np.abs(pt.render()).max()) == 0.0
         import copy
+        nm = copy.copy(sd)
+        nm._keep = []
+        nm.materials = [copy.copy(m) for m in sd.materials]
+        nm.materials[0].has_normal_map = 1
+        nm.materials[0].normal_image = 5   # the scene has no images
+        with pytest.raises(abi.RtxError, match="normal map index"):
+            pt.upload_scene(nm)
+        pt.upload_scene(sd)
         bad = copy.copy(sd)
         bad._keep = []
         s = abi.Sphere()
