@@ -52,8 +52,12 @@ int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, cons
   }
   else if (L.mode == MODE_TREE && L.lds_mats)
     hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+  else if (L.mode == MODE_TREE_UV && L.lds_mats && sc.n_nmaps == 0)
+    hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, true, INTEG_PATH, 32>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
   else if (L.mode == MODE_TREE_UV && L.lds_mats)
     hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+  else if (!L.lds_mats && L.mode != MODE_FLAT && sc.n_nmaps == 0)
+    hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, false, INTEG_PATH, 32>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
   else if (!L.lds_mats && L.mode != MODE_FLAT)
     hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, false>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
   else

@@ -1335,7 +1335,7 @@ RTX_DEV uint32_t whitted_vertex(PathState<R>& ps, const bool hit, Hit<R>& rec, c
 
 // Fused form: trace, shade, and trace the shadow ray(s) in place.  `extra_traces` counts the closest-hit
 // queries MNEE makes, `extra_shadow` the shadow queries of the Whitted integrator.
-template <class R, int MODE, int INTEG = INTEG_PATH>
+template <class R, int MODE, int INTEG = INTEG_PATH, bool NMAP = (MODE == MODE_TREE_UV)>
 RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMaterial<R>* mats, const DRenderParams& P, PathKey key, LaneStack st, uint32_t& extra_traces,
                            uint32_t& extra_shadow) {
   Hit<R> rec;
@@ -1343,7 +1343,7 @@ RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMateria
   if constexpr (INTEG == INTEG_WHITTED) {
     return whitted_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<R>& sr, R t_max) { return trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st); }, extra_shadow);
   } else {
-    return path_vertex_impl<R, INTEG == INTEG_PATH_MNEE, MODE == MODE_TREE_UV>(
+    return path_vertex_impl<R, INTEG == INTEG_PATH_MNEE, NMAP>(
         ps, hit, rec, sc, mats, P, key,
         [&](const Ray<R>& sr, R t_max, V3<R> contrib) {
           const bool visible = !trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st);

@@ -373,6 +373,8 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
   sc.n_spheres = (int)d.n_spheres; sc.n_planes = (int)d.n_planes; sc.n_tris = (int)d.n_triangles; sc.n_boxes = (int)d.n_boxes;
   sc.n_points = (int)d.n_point_lights; sc.n_quads = (int)d.n_quad_lights; sc.n_disks = (int)d.n_disk_lights; sc.n_mats = (int)d.n_materials;
   sc.n_images = (int)d.n_images; sc.n_emissive = (int)emissive.size();
+  sc.n_nmaps = 0;
+  for (size_t i = 0; i < d.n_materials; ++i) sc.n_nmaps += d.materials[i].has_normal_map ? 1 : 0;
   sc.n_nodes = (int)bvh.nodes.size(); sc.n_prims = (int)bvh.prims.size();
   if (d_env_texels) {
     std::vector<R> mg(marginal.begin(), marginal.end()), cd(conditional.begin(), conditional.end());

@@ -84,6 +84,7 @@ template <class R> struct DScene {
   const DFlatRec* flat;                                // flat scenes only (single precision)
   int32_t n_spheres, n_planes, n_tris, n_boxes, n_points, n_quads, n_disks, n_mats, n_images, n_emissive;
   int32_t n_nodes, n_prims, n_pairs, n_wide;
+  int32_t n_nmaps;                                     // materials with a normal map (picks the kernel instances that apply them)
   DEnv<R> env;
 };
 

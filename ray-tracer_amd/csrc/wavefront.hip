@@ -282,7 +282,7 @@ template <int MODE> RTX_DEV bool wf_load_hit(const DScene<float>& sc, const WfAr
   return true;
 }
 
-template <int MODE, bool LDS_MATS>
+template <int MODE, bool LDS_MATS, bool NMAP = false>
 __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DRenderParams P, WfArrays A, WfControl* ctl, int q, DCounters* counters) {
   const DMaterial<float>* mats = sc.mats;
   if constexpr (LDS_MATS) mats = stage_materials(sc);
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DRend
   PathKey key = {A.pixel[slot], P.seed, A.sample[slot] - 1u, (uint32_t)P.rng};
   Hit<float> rec;
   const bool hit = wf_load_hit<MODE>(sc, A, slot, ps.ray, rec);
-  did = path_vertex<float, MODE == MODE_TREE_UV>(ps, hit, rec, sc, mats, P, key, [&](const Ray<float>& sr, float t_max, V3<float> contrib) {
+  did = path_vertex<float, NMAP>(ps, hit, rec, sc, mats, P, key, [&](const Ray<float>& sr, float t_max, V3<float> contrib) {
     cast = true; sh_ray = sr; sh_tmax = t_max; sh_contrib = contrib;
   });
   A.ray[0][slot] = ps.ray.o.x; A.ray[1][slot] = ps.ray.o.y; A.ray[2][slot] = ps.ray.o.z;
@@ -393,7 +393,10 @@ template <int MODE> void launch_iteration_kernels(const DScene<float>& sc, const
     hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, qb, stack_levels, spill);
     ++launches;
   } else if (step == 1) {
-    if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, P, A, ctl, qa, counters);
+    if (MODE == MODE_TREE_UV && sc.n_nmaps > 0) {   // the instances that apply normal maps
+      if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true, MODE == MODE_TREE_UV>), g, bs, mat_lds, stream, sc, P, A, ctl, qa, counters);
+      else hipLaunchKernelGGL((wf_shade<MODE, false, MODE == MODE_TREE_UV>), g, bs, 0, stream, sc, P, A, ctl, qa, counters);
+    } else if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, P, A, ctl, qa, counters);
     else hipLaunchKernelGGL((wf_shade<MODE, false>), g, bs, 0, stream, sc, P, A, ctl, qa, counters);
   } else
     hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, stack_levels, spill);
