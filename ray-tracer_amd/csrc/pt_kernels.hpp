@@ -66,8 +66,7 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #endif
 // LEAN (bit mask) compiles scene features out of an instance by pinning the scene's counts to zero, so that every
 // branch on them folds away: 1 = no environment map, 2 = no point and no disk lights, 4 = no quad lights,
-// 8 = NEE and MIS on, 16 = the pcg4d generator, 32 = no material has a normal map (the tangent-frame code costs the
-// u/v-resolving instance a third of its speed through register pressure alone: earth_demo 1.55 s with, 2.10 s without this bit).
+// 8 = NEE and MIS on, 16 = the pcg4d generator, 32 = no material has a normal map (the tangent-frame code is left out).
 template <class R, int MODE, bool LDS_MATS, int INTEG = INTEG_PATH, int LEAN = 0>
 __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? ((LEAN & 1) ? RTX_LEAN_MIN_WAVES : (LEAN ? RTX_LEAN_ENV_MIN_WAVES : RTX_FLAT_MIN_WAVES)) : (INTEG == INTEG_PATH_MNEE ? RTX_MNEE_MIN_WAVES : (sizeof(R) == 4 ? RTX_TREE_MIN_WAVES : 1)))) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
                                                                DCounters* __restrict__ counters, int stack_first_int) {
