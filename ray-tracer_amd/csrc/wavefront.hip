@@ -54,6 +54,9 @@ constexpr int kRefillBelow = RTX_REFILL_BELOW;
 #endif
 constexpr int kLeafBatch = RTX_LEAF_BATCH;
 
+#ifndef RTX_POOL_MULT
+#define RTX_POOL_MULT 128   // path slots per resident lane (164 B each: 11 GB at most on 256 CUs); 10 M triangles at 1080p x 64 spp: 16: 839 ms, 32: 762, 64 and up (every work item in flight): 721
+#endif
 constexpr int kWfArrays = 6 + 3 + 3 + 3 + 1 + 7 + 3 + 2 + 2 + 1 + 7 + 3;   // 4-byte arrays of n_slots entries
 
 // Append to a queue from (possibly divergent) code: the active lanes of the wave take
@@ -422,7 +425,7 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   const unsigned long long items = npix * (unsigned long long)P.n_chunks;
   if (items >= 0x7fffffffull) { err = "film too large for one launch"; return RTX_ERR_INVALID_ARGUMENT; }
   // Pool size: enough slots to keep every CU at full occupancy several times over.
-  const uint32_t n_slots = (uint32_t)std::min<unsigned long long>(items, (unsigned long long)n_cus * 2048ull * 32ull);
+  const uint32_t n_slots = (uint32_t)std::min<unsigned long long>(items, (unsigned long long)n_cus * 2048ull * (unsigned long long)RTX_POOL_MULT);
   if (!pool.state.ensure((size_t)kWfArrays * n_slots * 4) || !pool.control.ensure(sizeof(WfControl)) ||
       !pool.queues.ensure((size_t)items * 3 * sizeof(float))) { err = "pool allocation"; return RTX_ERR_OUT_OF_MEMORY; }
   WfArrays A;
