@@ -467,3 +467,32 @@ def test_postprocess_device_buffers_and_errors(pkg, oracle):
         assert np.array_equal(out.cpu().numpy(), oracle.postprocess(film.cpu().numpy(), pkg.scene_loader.TM_ACES, 0.8))
         with pytest.raises(pkg.abi.RtxError, match="tone mapper"):
             pt.postprocess(np.zeros((2, 2, 3), np.float32), 9, 1.0)
+
+
+SIZES = ((1, 1, 1, 1), (1, 1, 5000, 3), (65535, 1, 1, 2), (1, 4097, 2, 0), (33, 17, 17, 1), (7, 5, 3, 100000))
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "kitchen_sink", "normal_mapped", "environment_demo"])
+def test_corner_sizes_all_modes(name, pkg, tracer, load_scene):
+    """Corner sizes through every mode, pipeline and precision: 1x1 films, one row of the maximum width, one column taller
+    than a workgroup, zero depth, sample counts far above the chunk size, depths far above any path's length.  Every render
+    must come back finite and of the right shape (no hang, no fault, no NaN)."""
+    abi = pkg.abi
+    sd = load_scene(name)
+    pt = tracer(sd)
+    n = 0
+    for (W, H, spp, depth) in SIZES:
+        pt.set_camera(sd.camera(W, H))
+        for mode in (abi.MODE_WHITTED, abi.MODE_PATHTRACE, abi.MODE_BDPT):
+            for pipe in (abi.PIPELINE_FUSED, abi.PIPELINE_WAVEFRONT):
+                for prec in (abi.PRECISION_F32, abi.PRECISION_F64):
+                    if pipe == abi.PIPELINE_WAVEFRONT and (mode != abi.MODE_PATHTRACE or prec == abi.PRECISION_F64):
+                        continue   # the queue pipeline is single-precision path tracing only
+                    pt.set_settings(sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=depth, mode=mode, pipeline=pipe, precision=prec))
+                    film = pt.render()
+                    assert film.shape == (H, W, 3) and np.isfinite(film).all(), (W, H, spp, depth, mode, pipe, prec)
+                    assert pt.last_stats.samples == W * H * spp
+                    if depth == 0:
+                        assert float(np.abs(film).max()) == 0.0 or mode == abi.MODE_WHITTED   # no bounce allowed: black
+                    n += 1
+    assert n == 6 * 7
