@@ -5,7 +5,8 @@
 //        -> ray-tracer_amd/host/reference_adapter.hpp -> C ABI -> MI355X kernels      (film A)
 //        -> the REFERENCE's own Renderer::render on the host cores (use_mnee = false)  (film B)
 //
-//   ref_hip_driver <scene.json> <W> <H> <spp_gpu> <spp_cpu> <depth> <threads> <out_prefix> [cpu_seed]
+//   ref_hip_driver <scene.json> <W> <H> <spp_gpu> <spp_cpu> <depth> <threads> <out_prefix> [cpu_seed [mode]]
+// (mode: RenderMode value, 1 = PathTrace by default, 0 = Whitted, 2 = BDPT; both renderers use it)
 // writes <out_prefix>_gpu.bin (float32) and <out_prefix>_cpu.bin (float64, unclamped) and
 // prints timings.  spp_cpu = 0 skips the CPU render.
 #include <omp.h>
@@ -32,7 +33,8 @@ int main(int argc, char** argv) {
   auto data = SceneLoader::load(argv[1]);
   Renderer::Settings st;
   st.width = W; st.height = H; st.samples_per_pixel = spp_gpu; st.max_depth = depth;
-  st.mode = RenderMode::PathTrace; st.use_nee = data.use_nee; st.use_mis = data.use_mis; st.use_mnee = false;
+  const int mode = argc > 10 ? atoi(argv[10]) : 1;
+  st.mode = mode == 0 ? RenderMode::Whitted : mode == 2 ? RenderMode::BDPT : RenderMode::PathTrace; st.use_nee = data.use_nee; st.use_mis = data.use_mis; st.use_mnee = false;
   st.background_color = data.background_color; st.background_top = data.background_top;
   st.background_bottom = data.background_bottom; st.use_background_gradient = data.use_background_gradient;
   Camera cam(data.camera_position, data.camera_target, data.camera_up, data.camera_fov, (double)W / H);

@@ -18,12 +18,15 @@ DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_hip_driver")
 
 
 @pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/ref_hip_driver not built (needs /root/reference at build time)")
-@pytest.mark.parametrize("name,depth", [("cornell_box", 500), ("cornell_box_quad", 50), ("caustics_test", 16), ("environment_demo", 50)])
+@pytest.mark.parametrize("name,depth", [("cornell_box", 500), ("cornell_box_quad", 50), ("caustics_test", 16), ("environment_demo", 50),
+                                        ("caustics_test_bdpt", 16), ("cornell_box_quad_bdpt", 12)])
 def test_reference_loader_feeds_hip_backend_and_matches_reference_renderer(name, depth, tmp_path):
     fx = np.load(os.path.join(GOLDEN, "converged", name + ".npz"))
     W, H, N = int(fx["W"]), int(fx["H"]), int(fx["N"])
     prefix = str(tmp_path / name)
-    out = subprocess.run([DRIVER, os.path.join(GOLDEN, "scenes", name + ".json"), str(W), str(H), str(N), str(N), str(depth), "16", prefix, "99"],
+    mode = str(int(fx["mode"])) if "mode" in fx else "1"      # *_bdpt: both renderers in RenderMode::BDPT
+    scene = name[:-5] if name.endswith("_bdpt") else name
+    out = subprocess.run([DRIVER, os.path.join(GOLDEN, "scenes", scene + ".json"), str(W), str(H), str(N), str(N), str(depth), "16", prefix, "99", mode],
                          cwd=GOLDEN, check=True, capture_output=True, text=True, timeout=110).stdout
     gpu = np.fromfile(prefix + "_gpu.bin", dtype=np.float32).reshape(H, W, 3).astype(np.float64)
     cpu = np.fromfile(prefix + "_cpu.bin", dtype=np.float64).reshape(H, W, 3)
