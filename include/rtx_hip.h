@@ -109,7 +109,7 @@ enum { RTX_PIPELINE_AUTO = 0, RTX_PIPELINE_FUSED = 1, RTX_PIPELINE_WAVEFRONT = 2
  * Whitted = Renderer::ray_color_whitted (engine/renderer.cpp:483-569), PathTrace = ray_color_path (:580-841),
  * BDPT = BDPTIntegrator::Li (engine/bdpt.cpp:71-128; max_eye_depth = max_light_depth = max_depth as in
  * engine/renderer.cpp:304-313).  Any other value returns RTX_ERR_UNSUPPORTED. */
-enum { RTX_MODE_WHITTED = 0, RTX_MODE_PATHTRACE = 1, RTX_MODE_BDPT = 2 };
+enum { RTX_MODE_WHITTED = 0, RTX_MODE_PATHTRACE = 1, RTX_MODE_BDPT = 2, RTX_MODE_PATHPHOTON = 6 };
 /* Counter-based generator behind the samples (the reference's per-thread mt19937 has no parallel counterpart):
  * AUTO = PCG4D for single precision, PHILOX for double; PHILOX = Philox-4x32-10 (Random123), the generator the
  * double-precision parity mode and the CPU oracle share; PCG4D = the pcg4d hash, a third of the multiplies. */
@@ -133,6 +133,10 @@ typedef struct rtx_settings {
   int32_t mode;                             /* RTX_MODE_* (Renderer::Settings::mode); Whitted runs in the fused pipeline */
   int32_t rng;                              /* RTX_RNG_* */
   double clamp_max;                         /* Renderer::Settings::clamp_max: luminance cap per BDPT strategy, <= 0 = off (engine/bdpt.cpp:114-121) */
+  /* PathPhoton mode (Renderer::Settings, engine/renderer.hpp:126-132; engine/renderer.cpp:344-372) */
+  uint64_t caustic_photon_count;            /* caustic photons emitted (default 50000) */
+  int32_t photon_gather_count;              /* photons gathered per estimate (default 100) */
+  float caustic_gather_radius;              /* gather radius, a float in the reference too (default 0.1f) */
 } rtx_settings;
 
 typedef struct rtx_stats {

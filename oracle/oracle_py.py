@@ -132,3 +132,11 @@ def philox(ctr, key):
     o = np.zeros(4, dtype=np.uint32)
     lib().orc_philox4x32_10(c.ctypes.data, k.ctypes.data, o.ctypes.data)
     return o
+
+
+def set_photon_aim_seed(seed):
+    """PathPhoton with RNG_MT19937: the seed of the reference's thread-id-seeded aim generator in the run to reproduce."""
+    L = lib()
+    L.orc_set_photon_aim_seed.argtypes = [C.c_ulonglong]
+    L.orc_set_photon_aim_seed.restype = None
+    L.orc_set_photon_aim_seed(int(seed))

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <queue>
 #include <random>
 #include <vector>
 
@@ -1580,6 +1581,299 @@ V3 bdpt_radiance(const orc_scene& s, const rtx_settings& st, Ray r, S& rng, Tall
   return L;
 }
 
+
+// ----------------------------------------------------------------------------------------
+// PathPhoton mode — engine/renderer.cpp:344-372 (photon pass), :844-976 (ray_color_path_with_caustics),
+// engine/photon_integrator.hpp:93-293 (caustic photons), engine/photon_map.hpp (kd-tree, k-nearest estimate).
+// The reference draws the photon pass from two generators: PhotonIntegrator::rng_ (seed 42) and, for the aim point
+// of every photon, a thread_local std::mt19937 seeded with the hash of the calling thread's id
+// (photon_integrator.hpp:457-459), which differs from process to process; g_photon_aim_seed carries the value a
+// particular reference run used (the harness prints it), so that run can be reproduced bit for bit.
+// ----------------------------------------------------------------------------------------
+unsigned long long g_photon_aim_seed = 0;
+struct PhotonMapO;
+const PhotonMapO* g_photon_map = nullptr;   // the map of the render in progress (one render at a time)
+
+struct OPhoton { V3 p, dir, power; uint8_t axis = 0; };
+
+struct PhotonMapO {   // photon_map.hpp:70-317, with the same standard-library algorithms
+  std::vector<OPhoton> ph;
+  static double ax(const V3& p, int a) { return a == 0 ? p.x : a == 1 ? p.y : p.z; }
+  void build_tree(size_t start, size_t end, int depth) {
+    if (end - start <= 1) return;
+    int axis = depth % 3;
+    size_t mid = start + (end - start) / 2;
+    std::nth_element(ph.begin() + start, ph.begin() + mid, ph.begin() + end,
+                     [axis](const OPhoton& a, const OPhoton& b) { return ax(a.p, axis) < ax(b.p, axis); });
+    ph[mid].axis = (uint8_t)axis;
+    build_tree(start, mid, depth + 1);
+    build_tree(mid + 1, end, depth + 1);
+  }
+  void build() { if (!ph.empty()) build_tree(0, ph.size(), 0); }
+  struct Res { const OPhoton* p; double d2; bool operator<(const Res& o) const { return d2 < o.d2; } };
+  void search(size_t start, size_t end, V3 pos, int k, double max_d2, std::priority_queue<Res>& heap) const {
+    if (start >= end) return;
+    size_t mid = start + (end - start) / 2;
+    const OPhoton& q = ph[mid];
+    double d2 = len2(sub(q.p, pos));
+    double rad = max_d2;
+    if ((int)heap.size() >= k) rad = std::min(rad, heap.top().d2);
+    if (d2 < rad) {
+      Res r{&q, d2};
+      if ((int)heap.size() < k) heap.push(r);
+      else if (d2 < heap.top().d2) { heap.pop(); heap.push(r); }
+    }
+    int axis = q.axis;
+    double delta = ax(pos, axis) - ax(q.p, axis);
+    double delta2 = delta * delta;
+    if (delta < 0) {
+      search(start, mid, pos, k, max_d2, heap);
+      if ((int)heap.size() < k || delta2 < heap.top().d2) search(mid + 1, end, pos, k, max_d2, heap);
+    } else {
+      search(mid + 1, end, pos, k, max_d2, heap);
+      if ((int)heap.size() < k || delta2 < heap.top().d2) search(start, mid, pos, k, max_d2, heap);
+    }
+  }
+  V3 estimate(V3 pos, V3 normal, int k, double max_radius) const {   // estimate_irradiance, photon_map.hpp:150-186
+    double max_d2 = max_radius * max_radius;
+    if (ph.empty()) return {0, 0, 0};
+    std::priority_queue<Res> heap;
+    search(0, ph.size(), pos, k, max_d2, heap);
+    std::vector<Res> near;
+    near.reserve(heap.size());
+    while (!heap.empty()) { near.push_back(heap.top()); heap.pop(); }
+    std::reverse(near.begin(), near.end());
+    if (near.empty()) return {0, 0, 0};
+    double r2 = near.back().d2;
+    if (r2 < 1e-10) r2 = 1e-10;
+    V3 flux = {0, 0, 0};
+    for (const Res& r : near) {
+      double cos_theta = -dot(r.p->dir, normal);
+      if (cos_theta <= 0) continue;
+      double w = 1.0 - std::sqrt(r.d2 / r2);
+      flux = add(flux, scale(r.p->power, w));
+    }
+    double area = kPi * r2;
+    return scale(flux, 3.0 / area);
+  }
+};
+
+// the draws of the photon pass, in the reference's order
+struct PhotonMt {
+  std::mt19937 rng{42};          // PhotonIntegrator::rng_, photon_integrator.hpp:46
+  std::mt19937 aim;              // sample_sphere()'s thread_local generator
+  std::uniform_real_distribution<double> dist{0.0, 1.0};
+  void begin(uint64_t) {}
+  double pick() { return dist(rng); }
+  double light_u() { return dist(rng); }
+  double light_v() { return dist(rng); }
+  double aim_u() { return dist(aim); }
+  double aim_v() { return dist(aim); }
+  double roulette(int) { return dist(rng); }
+  double fresnel(int) { return dist(rng); }
+  void lambert(int) { (void)dist(rng); }   // drawn and, in the caustic pass, not used (photon_integrator.hpp:284-286)
+};
+// counter-based: photon i is "pixel" i, sample 0xfffffffe; block 0 = pick | -, light u | v, aim u | v; block 1 + depth = roulette, fresnel
+struct PhotonCounter {
+  CounterSampler cs;
+  uint32_t seed = 0;
+  uint32_t b0[4], bd[4];
+  int have_d = -1;
+  void begin(uint64_t i) { cs.begin_sample((uint32_t)i, seed, 0xfffffffeu); cs.block(0u, b0); have_d = -1; }
+  uint32_t* D(int depth) { if (have_d != depth) { cs.block(1u + (uint32_t)depth, bd); have_d = depth; } return bd; }
+  double pick() { return CounterSampler::hi(b0[2]); }
+  double light_u() { return CounterSampler::hi(b0[0]); }
+  double light_v() { return CounterSampler::lo(b0[0]); }
+  double aim_u() { return CounterSampler::hi(b0[1]); }
+  double aim_v() { return CounterSampler::lo(b0[1]); }
+  double roulette(int d) { return CounterSampler::lo(D(d)[2]); }
+  double fresnel(int d) { return CounterSampler::hi(D(d)[3]); }
+  void lambert(int) {}
+};
+
+template <class PS>
+void trace_photon(const orc_scene& s, Ray r, V3 power, int depth, bool hit_specular, PS& ps, PhotonMapO& map, Tally& tl) {   // photon_integrator.hpp:202-293, caustic_only = true
+  for (;;) {   // the reference recurses; every branch is a tail call
+    if (depth >= 10) return;
+    double max_component = std::max({power.x, power.y, power.z});
+    if (depth > 3) {
+      double cp = std::min(0.9, max_component);
+      if (ps.roulette(depth) > cp) return;
+      power = scale(power, 1.0 / cp);
+    }
+    Hit rec;
+    tl.closest++;
+    if (!scene_hit(s, r, 0.001, 1e30, rec)) return;
+    if (rec.mat < 0) return;   // a quad / disk light: the reference indexes materials[negative] (undefined); defined as "the photon is lost"
+    const rtx_material& m = s.mats[rec.mat];
+    if (m.type == RTX_MAT_DIELECTRIC) {
+      V3 outward; double ni_over_nt, cosine;
+      if (dot(r.d, rec.n) > 0) { outward = neg(rec.n); ni_over_nt = m.refraction_index; cosine = m.refraction_index * dot(r.d, rec.n); }
+      else { outward = rec.n; ni_over_nt = 1.0 / m.refraction_index; cosine = -dot(r.d, rec.n); }
+      V3 refracted{0, 0, 0};
+      double reflect_prob = 1.0;
+      {  // refract_vec, :477-489
+        V3 uv = normalize(r.d);
+        double dt = dot(uv, outward);
+        double disc = 1.0 - ni_over_nt * ni_over_nt * (1.0 - dt * dt);
+        if (disc > 0) {
+          refracted = sub(scale(sub(uv, scale(outward, dt)), ni_over_nt), scale(outward, std::sqrt(disc)));
+          double r0 = (1.0 - m.refraction_index) / (1.0 + m.refraction_index);   // schlick, :491-495
+          r0 = r0 * r0;
+          reflect_prob = r0 + (1.0 - r0) * std::pow(1.0 - cosine, 5.0);
+        }
+      }
+      if (ps.fresnel(depth) < reflect_prob) {
+        V3 refl = sub(r.d, scale(rec.n, 2.0 * dot(r.d, rec.n)));
+        r = Ray{add(rec.p, scale(refl, 0.001)), refl};
+      } else {
+        power = mul(power, mk(m.albedo));
+        r = Ray{add(rec.p, scale(refracted, 0.001)), refracted};
+      }
+      depth++; hit_specular = true;
+      continue;
+    }
+    if (m.type == RTX_MAT_METAL) {
+      V3 refl = sub(r.d, scale(rec.n, 2.0 * dot(r.d, rec.n)));
+      power = mul(power, mk(m.albedo));
+      r = Ray{add(rec.p, scale(refl, 0.001)), refl};
+      depth++; hit_specular = true;
+      continue;
+    }
+    if (m.type == RTX_MAT_LAMBERTIAN) {
+      if (hit_specular) { OPhoton q; q.p = rec.p; q.dir = neg(r.d); q.power = power; map.ph.push_back(q); }
+      ps.lambert(depth);
+    }
+    return;
+  }
+}
+
+template <class PS>
+void trace_caustic_photons(const orc_scene& s, size_t n_caustic, PS& ps, PhotonMapO& map, Tally& tl) {   // photon_integrator.hpp:93-200
+  std::vector<size_t> lights;
+  double total_power = 0.0;
+  for (size_t i = 0; i < s.spheres.size(); ++i) {
+    const rtx_material& m = s.mats[s.spheres[i].material_id];
+    if (m.emission[0] > 0 || m.emission[1] > 0 || m.emission[2] > 0) { lights.push_back(i); total_power += (m.emission[0] + m.emission[1] + m.emission[2]) / 3.0; }
+  }
+  if (lights.empty()) return;
+  std::vector<size_t> targets;
+  for (size_t i = 0; i < s.spheres.size(); ++i) {
+    const rtx_material& m = s.mats[s.spheres[i].material_id];
+    if (m.type == RTX_MAT_DIELECTRIC || m.type == RTX_MAT_METAL || m.fuzz < 0.1) targets.push_back(i);
+  }
+  if (targets.empty()) return;
+  uint64_t photon_index = 0;
+  for (size_t li : lights) {
+    const rtx_sphere& ls = s.spheres[li];
+    const rtx_material& lm = s.mats[ls.material_id];
+    double light_power = (lm.emission[0] + lm.emission[1] + lm.emission[2]) / 3.0;
+    double fraction = light_power / total_power;
+    size_t n = (size_t)(n_caustic * fraction);
+    double area = 4.0 * kPi * ls.radius * ls.radius;
+    V3 photon_power = scale(mk(lm.emission), area / (double)n);
+    for (size_t i = 0; i < n; ++i, ++photon_index) {
+      ps.begin(photon_index);
+      size_t ti = targets[(size_t)(ps.pick() * targets.size()) % targets.size()];
+      const rtx_sphere& tg = s.spheres[ti];
+      double u = ps.light_u(), v = ps.light_v();
+      double theta = 2.0 * kPi * u, phi = std::acos(2.0 * v - 1.0);
+      V3 local = {std::sin(phi) * std::cos(theta), std::sin(phi) * std::sin(theta), std::cos(phi)};
+      V3 origin = add(mk(ls.center), scale(local, ls.radius * 1.001));
+      double au = ps.aim_u(), av = ps.aim_v();   // sample_sphere, :457-471
+      double at = 2.0 * kPi * au, ap = std::acos(2.0 * av - 1.0);
+      V3 sp = {std::sin(ap) * std::cos(at), std::sin(ap) * std::sin(at), std::cos(ap)};
+      V3 target_point = add(mk(tg.center), scale(sp, tg.radius * 0.5));
+      V3 to_target = sub(target_point, origin);
+      V3 dir = normalize(to_target);
+      double dist_sq = len2(to_target);
+      double solid_angle = kPi * tg.radius * tg.radius / dist_sq;
+      V3 adjusted = scale(photon_power, 4.0 * kPi / solid_angle);
+      trace_photon(s, Ray{origin, dir}, adjusted, 0, true, ps, map, tl);
+    }
+  }
+}
+
+// Renderer::ray_color_path_with_caustics — engine/renderer.cpp:844-976
+template <class S>
+V3 pathphoton_radiance(const orc_scene& s, const rtx_settings& st, Ray r, const PhotonMapO& map, S& rng, Tally& tl) {
+  V3 thr = {1.0, 1.0, 1.0}, acc = {0.0, 0.0, 0.0};
+  Ray cur = r;
+  bool spec = false;
+  const bool nee = st.use_nee != 0;
+  for (int bounce = 0; bounce < st.max_depth; ++bounce) {
+    rng.begin_bounce(bounce);
+    Hit rec;
+    tl.closest++;
+    if (!scene_hit(s, cur, 0.001, 1e9, rec)) { acc = add(acc, mul(thr, background(s, st, cur))); break; }
+    tl.segments++;
+    if (rec.mat < 0) {
+      if (bounce == 0 || spec || !nee) acc = add(acc, mul(thr, area_light_emission(s, rec.mat)));
+      break;
+    }
+    const rtx_material& m = s.mats[rec.mat];
+    apply_normal_map(s, m, rec);
+    V3 surf = albedo_at(s, m, rec.p, rec.u, rec.v);
+    if (bounce == 0 || spec || !nee) acc = add(acc, mul(thr, mk(m.emission)));
+    V3 sdir{0, 0, 0};
+    V3 atten = surf;
+    spec = false;
+    if (m.type == RTX_MAT_LAMBERTIAN) {
+      if (!map.ph.empty()) {
+        V3 caustic = map.estimate(rec.p, rec.n, st.photon_gather_count, (double)st.caustic_gather_radius);
+        acc = add(acc, mul(thr, mul(surf, caustic)));
+      }
+      if (nee) {
+        LightPick ls = sample_light(s, rec.p, rng);
+        if (ls.valid) {
+          V3 to_light = sub(ls.pos, rec.p);
+          double ld = len(to_light);
+          V3 ldir = scale(to_light, 1.0 / ld);
+          double cs = dot(rec.n, ldir);
+          if (cs > 0) {
+            Hit sh;
+            bool is_env = ls.dist > 1e5;
+            double sd = is_env ? 1e9 : ld - 0.001;
+            tl.shadow++;
+            if (!scene_hit(s, Ray{rec.p, ldir}, 0.001, sd, sh)) {
+              double cl = std::abs(dot(ls.n, neg(ldir)));
+              double falloff = is_env ? 1.0 : 1.0 / (ld * ld);
+              V3 direct = scale(mul(surf, ls.Le), cs * falloff * cl / (ls.pdf * kPi));
+              acc = add(acc, mul(thr, direct));
+            }
+          }
+        }
+      }
+      sdir = add(rec.n, rng.unit_vector());
+      if (len2(sdir) < 1e-8) sdir = rec.n;
+      sdir = normalize(sdir);
+    } else if (m.type == RTX_MAT_METAL) {
+      spec = true;
+      V3 refl = reflect(normalize(cur.d), rec.n);
+      if (m.fuzz > 0.0) { refl = add(refl, scale(rng.unit_vector(), m.fuzz)); spec = (m.fuzz < 0.1); }
+      sdir = refl;   // both `break`s at :937-938 leave the switch only
+    } else if (m.type == RTX_MAT_DIELECTRIC) {
+      spec = true;
+      atten = {1.0, 1.0, 1.0};
+      double ratio = rec.front ? (1.0 / m.refraction_index) : m.refraction_index;
+      V3 ud = normalize(cur.d);
+      double ct = std::fmin(dot(neg(ud), rec.n), 1.0);
+      double sn = std::sqrt(1.0 - ct * ct);
+      if (ratio * sn > 1.0 || schlick(ct, ratio) > rng.fresnel()) sdir = reflect(ud, rec.n);
+      else sdir = refract(ud, rec.n, ratio);
+    } else return acc;
+    thr = mul(thr, atten);
+    if (bounce > 3) {
+      double p = std::fmax(thr.x, std::fmax(thr.y, thr.z));
+      if (p < 0.01) break;
+      if (rng.roulette() > p) break;
+      thr = scale(thr, 1.0 / p);
+    }
+    cur = Ray{rec.p, sdir};
+  }
+  return acc;
+}
+
 inline Ray camera_ray(const rtx_camera& c, double s, double t) {  // scene.hpp:99-108
   V3 o = mk(c.origin);
   V3 d = sub(add(add(mk(c.lower_left_corner), scale(mk(c.horizontal), s)), scale(mk(c.vertical), t)), o);
@@ -1595,7 +1889,8 @@ void render_rows(const orc_scene& s, const rtx_camera& cam, const rtx_settings& 
       double u = ((double)x + rng.jitter_x()) / st.width;
       double v = ((double)y + rng.jitter_y()) / st.height;
       Ray r = camera_ray(cam, u, v);
-      px = add(px, st.mode == RTX_MODE_WHITTED ? whitted_radiance(s, st, r, st.max_depth, 0, rng, tl) : st.mode == RTX_MODE_BDPT ? bdpt_radiance(s, st, r, rng, tl) : path_radiance(s, st, r, rng, tl));
+      px = add(px, st.mode == RTX_MODE_WHITTED ? whitted_radiance(s, st, r, st.max_depth, 0, rng, tl) : st.mode == RTX_MODE_BDPT ? bdpt_radiance(s, st, r, rng, tl)
+                   : st.mode == RTX_MODE_PATHPHOTON ? pathphoton_radiance(s, st, r, *g_photon_map, rng, tl) : path_radiance(s, st, r, rng, tl));
     }
     px = scale(px, 1.0 / st.samples_per_pixel);
     double* o = film + ((size_t)y * st.width + x) * 3;
@@ -1692,6 +1987,15 @@ int orc_render(const orc_scene* s, const rtx_camera* cam, const rtx_settings* st
   memset(film, 0, sizeof(double) * (size_t)W * H * 3);
   uint64_t closest = 0, shadow = 0, segments = 0, rows_done = 0;
   double t0 = omp_get_wtime();
+  PhotonMapO photon_map;
+  if (st->mode == RTX_MODE_PATHPHOTON) {   // engine/renderer.cpp:344-372: the photon pass comes first, on the calling thread
+    Tally ptl;
+    if (rng_mode == ORC_RNG_MT19937) { PhotonMt ps; ps.aim.seed(g_photon_aim_seed); trace_caustic_photons(*s, (size_t)st->caustic_photon_count, ps, photon_map, ptl); }
+    else { PhotonCounter ps; ps.cs.pcg = rng_mode == ORC_RNG_COUNTER_PCG; ps.seed = st->seed; trace_caustic_photons(*s, (size_t)st->caustic_photon_count, ps, photon_map, ptl); }
+    photon_map.build();
+    closest += ptl.closest;
+    g_photon_map = &photon_map;
+  }
   if (rng_mode == ORC_RNG_MT19937) {
     // One generator per thread seeded seed + thread id, rows handed out in order; with one
     // thread this is the reference's traversal order exactly.
@@ -1791,6 +2095,8 @@ double pp_tone(double x, int mapper) {                                          
   }
 }
 }  // namespace
+
+extern "C" void orc_set_photon_aim_seed(unsigned long long seed) { g_photon_aim_seed = seed; }
 
 extern "C" void orc_pcg4d(uint32_t pixel, uint32_t sample, uint32_t block, uint32_t seed, uint32_t out[4]) { pcg4d(pixel, sample, block, seed, out); }
 

@@ -50,6 +50,9 @@ int orc_postprocess(const float* film, int width, int height, int tone_mapper, d
 
 /* One block of the pcg4d generator for (pixel, sample, block, seed), exposed for statistical tests. */
 void orc_pcg4d(uint32_t pixel, uint32_t sample, uint32_t block, uint32_t seed, uint32_t out[4]);
+/* PathPhoton, ORC_RNG_MT19937 only: the seed the reference's thread-id-seeded aim generator had in the run to reproduce
+ * (engine/photon_integrator.hpp:457-459; printed by oracle/_ref/ref_harness as @@AIMSEED@@). */
+void orc_set_photon_aim_seed(unsigned long long seed);
 
 /* The counter-based generator, exposed so tests can pin it (Random123 known answers). */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

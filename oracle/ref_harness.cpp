@@ -30,6 +30,7 @@
 #include <cstring>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "scene_loader.hpp"  // reference header, found through -I/root/reference/engine
@@ -270,7 +271,15 @@ int cmd_render(int argc, char** argv) {
   auto d = SceneLoader::load(scene_path);
   Renderer::Settings st;
   st.width = W; st.height = H; st.samples_per_pixel = spp; st.max_depth = depth;
-  st.mode = (argc > 13 && atoi(argv[13]) == 0) ? RenderMode::Whitted : (argc > 13 && atoi(argv[13]) == 2) ? RenderMode::BDPT : RenderMode::PathTrace;   // optional 12th value: RenderMode
+  const int mode_arg = argc > 13 ? atoi(argv[13]) : 1;   // optional 12th value: RenderMode
+  st.mode = mode_arg == 0 ? RenderMode::Whitted : mode_arg == 2 ? RenderMode::BDPT : mode_arg == 6 ? RenderMode::PathPhoton : RenderMode::PathTrace;
+  // PathPhoton: optional caustic photon count, gather count, gather radius (Renderer::Settings defaults otherwise)
+  if (argc > 14) st.caustic_photon_count = (size_t)strtoull(argv[14], nullptr, 10);
+  if (argc > 15) st.photon_gather_count = atoi(argv[15]);
+  if (argc > 16) st.caustic_gather_radius = (float)atof(argv[16]);
+  // The photon pass aims every caustic photon with a generator seeded by the hash of the calling thread's id
+  // (engine/photon_integrator.hpp:457-459); it runs on this thread, so this is the seed it will use.
+  printf("@@AIMSEED@@ %llu\n", (unsigned long long)std::hash<std::thread::id>{}(std::this_thread::get_id()));
   st.use_nee = nee; st.use_mis = mis; st.use_mnee = mnee;
   st.tone_mapper = ToneMapper::None;
   // ToneMapper::None still clamps to [0,1] (engine/renderer.cpp:175-182).  Scaling by an

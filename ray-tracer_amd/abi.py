@@ -81,7 +81,8 @@ class Settings(C.Structure):
                 ("max_depth", C.c_int32), ("use_nee", C.c_int32), ("use_mis", C.c_int32), ("use_mnee", C.c_int32),
                 ("use_background_gradient", C.c_int32), ("background_color", d3), ("background_top", d3),
                 ("background_bottom", d3), ("seed", C.c_uint32), ("precision", C.c_int32), ("pipeline", C.c_int32),
-                ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("mode", C.c_int32), ("rng", C.c_int32), ("clamp_max", C.c_double)]
+                ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("mode", C.c_int32), ("rng", C.c_int32), ("clamp_max", C.c_double),
+                ("caustic_photon_count", C.c_uint64), ("photon_gather_count", C.c_int32), ("caustic_gather_radius", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -106,7 +107,7 @@ assert C.sizeof(Hit) == 96
 
 PRECISION_F32, PRECISION_F64 = 0, 1
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
-MODE_WHITTED, MODE_PATHTRACE, MODE_BDPT = 0, 1, 2
+MODE_WHITTED, MODE_PATHTRACE, MODE_BDPT, MODE_PATHPHOTON = 0, 1, 2, 6
 RNG_AUTO, RNG_PHILOX, RNG_PCG4D = 0, 1, 2
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2

@@ -106,7 +106,8 @@ template <class SettingsT> inline rtx_settings to_settings(const SettingsT& s) {
   r.use_background_gradient = s.use_background_gradient;
   put3(r.background_color, s.background_color); put3(r.background_top, s.background_top); put3(r.background_bottom, s.background_bottom);
   r.seed = 1234u; r.precision = RTX_PRECISION_F32; r.pipeline = RTX_PIPELINE_AUTO; r.shard_index = 0; r.shard_count = 1;
-  r.mode = (int32_t)s.mode; r.clamp_max = s.clamp_max;   // RenderMode values are kept (engine/renderer.hpp:26-34)
+  r.mode = (int32_t)s.mode; r.clamp_max = s.clamp_max;
+  r.caustic_photon_count = s.caustic_photon_count; r.photon_gather_count = s.photon_gather_count; r.caustic_gather_radius = s.caustic_gather_radius;   // RenderMode values are kept (engine/renderer.hpp:26-34)
   return r;
 }
 

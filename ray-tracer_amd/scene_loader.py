@@ -204,6 +204,9 @@ class SceneData:
     tone_mapper: int = TM_ACES
     exposure: float = 1.0
     clamp_max: float = 10.0
+    caustic_photon_count: int = 50000      # engine/scene_loader.hpp:56-61
+    photon_gather_count: int = 100
+    caustic_gather_radius: float = 0.1
     background_color: tuple = (0.0, 0.0, 0.0)
     background_top: tuple = (0.5, 0.7, 1.0)
     background_bottom: tuple = (1.0, 1.0, 1.0)
@@ -233,6 +236,7 @@ class SceneData:
         st.pipeline = abi.PIPELINE_AUTO
         st.shard_index, st.shard_count = 0, 1
         st.clamp_max = self.clamp_max
+        st.caustic_photon_count, st.photon_gather_count, st.caustic_gather_radius = self.caustic_photon_count, self.photon_gather_count, self.caustic_gather_radius
         st.mode = abi.MODE_PATHTRACE   # the hot path; pass mode=self.mode (or abi.MODE_WHITTED) for the scene file's own mode
         for k, v in over.items():
             if not hasattr(st, k):
@@ -536,6 +540,12 @@ def load(path: str, base_dir: str | None = None, image_loader=None) -> SceneData
         data.mode = _parse_mode(r.get("mode", "whitted"))
         tm = r.get("tonemapper", "aces")
         data.tone_mapper = {"none": TM_NONE, "reinhard": TM_REINHARD, "uncharted2": TM_UNCHARTED2}.get(tm, TM_ACES)
+
+    if "photon_mapping" in j:   # engine/scene_loader.hpp:369-378 (the members PathPhoton reads)
+        pm = j["photon_mapping"]
+        data.caustic_photon_count = int(pm.get("caustic_photon_count", 50000))
+        data.photon_gather_count = int(pm.get("gather_count", 100))
+        data.caustic_gather_radius = float(np.float32(pm.get("caustic_radius", 0.1)))
 
     if "background" in j:
         bg = j["background"]

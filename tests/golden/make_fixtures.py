@@ -120,10 +120,12 @@ def ref_bvh(name, tris=None):
     return nodes["box"].copy(), nodes["ints"].copy(), prims.copy()
 
 
-def ref_film(name, W, H, spp, depth, seed, nee=1, mis=1, mnee=0, threads=1, mode=1):
+def ref_film(name, W, H, spp, depth, seed, nee=1, mis=1, mnee=0, threads=1, mode=1, extra=(), info=None):
     with tempfile.TemporaryDirectory() as td:
         op = os.path.join(td, "film.bin")
-        out = run(["render", scene_path(name), W, H, spp, depth, seed, nee, mis, mnee, threads, op, mode]).stdout
+        out = run(["render", scene_path(name), W, H, spp, depth, seed, nee, mis, mnee, threads, op, mode] + list(extra)).stdout
+        if info is not None:
+            info["aim_seed"] = int([l for l in out.splitlines() if l.startswith("@@AIMSEED@@")][-1].split()[1])
         raw = np.fromfile(op, dtype=np.uint8)
     secs = float([l for l in out.splitlines() if l.startswith("@@TIME@@")][-1].split()[1])
     return np.frombuffer(raw[8:].tobytes(), dtype=np.float64).reshape(H, W, 3).copy(), secs
@@ -235,6 +237,24 @@ def make_bdpt_fixtures():
         print("film", tag, float(film.mean()))
 
 
+# RenderMode::PathPhoton (engine/renderer.cpp:344-372, :844-976).  Scenes whose lights are emissive spheres (only those emit
+# photons) and that have no quad / disk light (a photon landing on one indexes materials[negative] in the reference).
+# The reference aims its photons with a generator seeded by the hash of the thread id: the seed of each run is kept.
+PATHPHOTON_FILMS = [("cornell_box", 24, 14, 3, 10, 131, 1, 4000, 40, 0.3), ("cornell_box", 20, 12, 2, 8, 132, 0, 1500, 10, 0.1),
+                    ("kitchen_points", 24, 14, 3, 8, 133, 1, 3000, 25, 0.25), ("textured", 24, 14, 3, 8, 134, 1, 3000, 100, 0.5),
+                    ("normal_mapped", 24, 14, 3, 8, 135, 1, 3000, 30, 0.3)]
+
+
+def make_pathphoton_fixtures():
+    for (n, W, H, spp, depth, seed, nee, photons, k, radius) in PATHPHOTON_FILMS:
+        info = {}
+        film, _ = ref_film(n, W, H, spp, depth, seed, nee, 1, mode=6, extra=[photons, k, repr(radius)], info=info)
+        tag = f"{n}_{W}x{H}_s{spp}_d{depth}_seed{seed}_nee{nee}_pathphoton"
+        np.savez_compressed(os.path.join(HERE, "films", tag + ".npz"), film=film, scene=n, W=W, H=H, spp=spp, depth=depth, seed=seed, nee=nee, mis=1, mode=6,
+                            caustic_photon_count=photons, photon_gather_count=k, caustic_gather_radius=np.float32(radius), aim_seed=np.uint64(info["aim_seed"]))
+        print("film", tag, float(film.mean()), info)
+
+
 def make_bdpt_converged():
     """BDPT films of the real reference at 4N spp plus two N-spp films of other seeds (the Monte-Carlo noise floor)."""
     for n, depth in (("caustics_test", 16), ("cornell_box_quad", 12)):
@@ -263,6 +283,9 @@ def main():
         return
     if "--whitted-only" in sys.argv:
         make_whitted_fixtures()
+        return
+    if "--pathphoton-only" in sys.argv:
+        make_pathphoton_fixtures()
         return
     if "--bdpt-only" in sys.argv:
         make_bdpt_fixtures()
@@ -318,6 +341,7 @@ def main():
     make_whitted_fixtures()
     make_normal_map_fixtures()
     make_bdpt_fixtures()
+    make_pathphoton_fixtures()
 
     # --- converged references + noise floor ----------------------------------------------
     for n, depth in (("cornell_box", 500), ("cornell_box_quad", 50), ("caustics_test", 16), ("environment_demo", 50), ("kitchen_sink", 24)):

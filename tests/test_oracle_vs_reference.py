@@ -145,6 +145,9 @@ def test_seeded_film_bit_exact(path, oracle, load_scene):
     st = sd.settings(width=W, height=H, samples_per_pixel=int(fx["spp"]), max_depth=int(fx["depth"]), seed=int(fx["seed"]),
                      use_nee=int(fx["nee"]), use_mis=int(fx["mis"]), use_mnee=int(fx["mnee"]) if "mnee" in fx else 0,
                      mode=int(fx["mode"]) if "mode" in fx else 1)
+    if "aim_seed" in fx:   # PathPhoton: photon counts and the seed the reference's thread-id-seeded aim generator had in that run
+        st.caustic_photon_count, st.photon_gather_count, st.caustic_gather_radius = int(fx["caustic_photon_count"]), int(fx["photon_gather_count"]), float(fx["caustic_gather_radius"])
+        oracle.set_photon_aim_seed(int(fx["aim_seed"]))
     film, _ = oracle.OracleScene(sd).render(sd.camera(W, H), st, oracle.RNG_MT19937, threads=1)
     if len(sd.quad_lights) and int(fx["nee"]) and int(fx["mis"]) and "mode" not in fx:
         # When a BSDF ray lands on a quad light the reference's look-ahead reads materials[-1]
