@@ -1,6 +1,7 @@
 // Single-precision instantiations: the production kernels.
 #include "pt_kernels.hpp"
 #include "pt_bdpt.hpp"
+#include "pt_photon_kernel.hpp"
 #include "pt_host.hpp"
 
 namespace rtx {
@@ -13,6 +14,12 @@ __global__ void selftest_kernel(float* out, int n) {
 
 void launch_selftest(float* out, int n, hipStream_t stream) {
   hipLaunchKernelGGL(selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n);
+}
+
+void launch_photon_trace(const DScene<float>& sc, const DRenderParams& P, const DPhotonLight* lights, int n_lights, const int32_t* targets, int n_targets,
+                         uint32_t n_photons, float* out, DCounters* counters, size_t lds_bytes, hipStream_t stream) {
+  const unsigned grid = (n_photons + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL((photon_trace_kernel<float, MODE_TREE_UV>), dim3(grid), dim3(kBlock), lds_bytes, stream, sc, P, lights, n_lights, targets, n_targets, n_photons, out, counters, 0);
 }
 
 int launch_render_bdpt(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters, const FusedLaunch& L,
@@ -28,6 +35,12 @@ int launch_render_bdpt(const DScene<float>& sc, const DCamera<float>& cam, const
 int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
                         const FusedLaunch& L, hipStream_t stream) {
   dim3 g(L.grid), b(kBlock);
+  if (L.integ == INTEG_PATHPHOTON) {   // as Whitted: the general (TREE_UV) instances only
+    if (L.mode != MODE_TREE_UV) return -1;
+    if (L.lds_mats) hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, true, INTEG_PATHPHOTON>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, false, INTEG_PATHPHOTON>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    return 0;
+  }
   if (L.integ == INTEG_WHITTED) {   // the Whitted integrator exists for the general (TREE_UV) instances only
     if (L.mode != MODE_TREE_UV) return -1;
     if (L.lds_mats) hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, true, INTEG_WHITTED>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);

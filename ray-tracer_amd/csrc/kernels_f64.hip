@@ -3,6 +3,7 @@
 // (baseline x86-64) rounds after every multiply and every add, and so must these.
 #include "pt_kernels.hpp"
 #include "pt_bdpt.hpp"
+#include "pt_photon_kernel.hpp"
 #include "pt_host.hpp"
 
 namespace rtx {
@@ -61,6 +62,12 @@ void launch_trace_ref(const DScene<double>& sc, const DSceneRef& ref, const doub
   hipLaunchKernelGGL(trace_ref_kernel, dim3(grid), dim3(64), 0, stream, sc, ref, rays8, n, out);
 }
 
+void launch_photon_trace(const DScene<double>& sc, const DRenderParams& P, const DPhotonLight* lights, int n_lights, const int32_t* targets, int n_targets,
+                         uint32_t n_photons, double* out, DCounters* counters, size_t lds_bytes, hipStream_t stream) {
+  const unsigned grid = (n_photons + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL((photon_trace_kernel<double, MODE_TREE_UV>), dim3(grid), dim3(kBlock), lds_bytes, stream, sc, P, lights, n_lights, targets, n_targets, n_photons, out, counters, 0);
+}
+
 int launch_render_bdpt(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters, const FusedLaunch& L,
                        double* light_store, unsigned long long store_cap, hipStream_t stream) {
   dim3 g(L.grid), b(kBlock);
@@ -82,6 +89,12 @@ int launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, co
       hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, false, INTEG_PATH_MNEE>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     else
       return -1;
+    return 0;
+  }
+  if (L.integ == INTEG_PATHPHOTON) {   // as Whitted: the general (TREE_UV) instances only
+    if (L.mode != MODE_TREE_UV) return -1;
+    if (L.lds_mats) hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, true, INTEG_PATHPHOTON>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE_UV, false, INTEG_PATHPHOTON>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     return 0;
   }
   if (L.integ == INTEG_WHITTED) {   // the Whitted integrator exists for the general (TREE_UV) instances only

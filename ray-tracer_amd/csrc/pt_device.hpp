@@ -1333,6 +1333,10 @@ RTX_DEV uint32_t whitted_vertex(PathState<R>& ps, const bool hit, Hit<R>& rec, c
   return STEP_SHADED;
 }
 
+}  // namespace rtx
+#include "pt_photon.hpp"
+namespace rtx {
+
 // Fused form: trace, shade, and trace the shadow ray(s) in place.  `extra_traces` counts the closest-hit
 // queries MNEE makes, `extra_shadow` the shadow queries of the Whitted integrator.
 template <class R, int MODE, int INTEG = INTEG_PATH, bool NMAP = (MODE == MODE_TREE_UV)>
@@ -1340,7 +1344,9 @@ RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMateria
                            uint32_t& extra_shadow) {
   Hit<R> rec;
   const bool hit = trace_closest<R, MODE>(sc, ps.ray, R(0.001), R(1e9), rec, st);
-  if constexpr (INTEG == INTEG_WHITTED) {
+  if constexpr (INTEG == INTEG_PATHPHOTON) {
+    return photon_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<R>& sr, R t_max) { return trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st); });
+  } else if constexpr (INTEG == INTEG_WHITTED) {
     return whitted_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<R>& sr, R t_max) { return trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st); }, extra_shadow);
   } else {
     return path_vertex_impl<R, INTEG == INTEG_PATH_MNEE, NMAP>(

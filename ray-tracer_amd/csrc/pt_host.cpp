@@ -425,6 +425,7 @@ void HostScene::release() {
   for (DeviceBuffer& b : pool) b.release();
   pool.clear();
   memset(&dev_f, 0, sizeof dev_f); memset(&dev_d, 0, sizeof dev_d); memset(&dev_ref, 0, sizeof dev_ref);
+  h_spheres.clear(); h_materials.clear();
   n_nodes = n_prims = 0;
 }
 
@@ -502,6 +503,8 @@ int HostScene::upload(const rtx_scene_desc& d, std::string& err) {
   fill_scene(dev_f, pool, d, bvh, emissive, d_images, d_prims, d_env, marginal, conditional, env_total, ok);
   lap("single-precision scene");
   dev_ref.nodes = d_nodes_ref; dev_ref.prims = d_prims; dev_ref.n_nodes = n_nodes; dev_ref.n_prims = n_prims;
+  h_spheres.assign(d.spheres, d.spheres + d.n_spheres);
+  h_materials.assign(d.materials, d.materials + d.n_materials);
   if (!ok) { release(); err = "device allocation or copy failed"; return RTX_ERR_OUT_OF_MEMORY; }
   return RTX_OK;
 }

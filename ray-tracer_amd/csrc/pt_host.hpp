@@ -48,6 +48,8 @@ struct HostScene {
   int n_nodes = 0, n_prims = 0;
   double build_seconds = 0.0;
   std::vector<DeviceBuffer> pool;   // owns every device allocation of the scene
+  std::vector<rtx_sphere> h_spheres;   // host copies the PathPhoton photon pass is planned from
+  std::vector<rtx_material> h_materials;
   int upload(const rtx_scene_desc& d, std::string& err);
   // Which intersection mode the integrator kernels use for this scene.
   int fused_mode(bool f64) const {
@@ -68,6 +70,11 @@ struct FusedLaunch {
   int stack_first_int;  // offset (in ints) of the traversal stacks inside the dynamic LDS
   int integ = INTEG_PATH;  // INTEG_*: path tracing, path tracing with MNEE (double precision only), Whitted (TREE_UV instances only)
 };
+// PathPhoton photon pass (pt_photon.hpp): `out` = 10 planes of n_photons values (position, -direction, power, valid)
+void launch_photon_trace(const DScene<float>& sc, const DRenderParams& P, const DPhotonLight* lights, int n_lights, const int32_t* targets, int n_targets,
+                         uint32_t n_photons, float* out, DCounters* counters, size_t lds_bytes, hipStream_t stream);
+void launch_photon_trace(const DScene<double>& sc, const DRenderParams& P, const DPhotonLight* lights, int n_lights, const int32_t* targets, int n_targets,
+                         uint32_t n_photons, double* out, DCounters* counters, size_t lds_bytes, hipStream_t stream);
 // BDPT (pt_bdpt.hpp): `light_store` holds kBdptFields * store_cap values per lane of the grid (store_cap = max_depth + 1 kept light vertices)
 int launch_render_bdpt(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters, const FusedLaunch& L,
                        float* light_store, unsigned long long store_cap, hipStream_t stream);

@@ -103,7 +103,17 @@ struct DRenderParams {
   int32_t rng;                              // RNG_PHILOX / RNG_PCG4D (pt_device.hpp)
   double bg[3], bg_top[3], bg_bottom[3];
   double clamp_max;                         // BDPT: luminance cap per strategy, <= 0 off
+  // PathPhoton: the caustic photon map of this render (pt_photon.hpp), DPhotonNode<R> / DPhotonData<R> arrays
+  const void* ph_nodes; const void* ph_data;
+  int32_t n_photons, gather_k;
+  double gather_radius;
 };
+
+// PathPhoton (pt_photon.hpp)
+constexpr int kPhotonMaxGather = 128;   // largest photon_gather_count the estimate keeps per lane
+struct DPhotonLight { int32_t sphere; uint32_t first, count; int32_t pad; double power[3]; };   // photons [first, first + count) leave this emissive sphere
+template <class R> struct DPhotonNode { R p[3]; int32_t axis; };       // kd-tree in the reference's implicit layout: the median of a range sits at its middle
+template <class R> struct DPhotonData { R dir[3]; R power[3]; };
 
 struct DCounters { unsigned long long samples, closest, shadow, segments; };
 
@@ -120,7 +130,7 @@ constexpr int kStackDepth = 48;      // per-lane traversal stack entries (LDS)
 // How a kernel instance intersects (see pt_device.hpp).
 enum { MODE_TREE = 0, MODE_TREE_UV = 1, MODE_FLAT = 2 };
 // Integrator a fused kernel instance runs: ray_color_path, ray_color_path with MNEE, ray_color_whitted.
-enum { INTEG_PATH = 0, INTEG_PATH_MNEE = 1, INTEG_WHITTED = 2, INTEG_BDPT = 3 };
+enum { INTEG_PATH = 0, INTEG_PATH_MNEE = 1, INTEG_WHITTED = 2, INTEG_BDPT = 3, INTEG_PATHPHOTON = 4 };
 constexpr int kBdptStoreFields = 18;   // values kept per connectible light-subpath vertex (pt_bdpt.hpp)
 constexpr int kFlatMaxSpheres = 16;   // flat mode: sphere-only bounded primitives, at most this many
 constexpr size_t kMaxLdsMaterialBytes = 32768;

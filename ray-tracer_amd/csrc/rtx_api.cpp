@@ -50,8 +50,89 @@ struct rtx_ctx {
   DCamera<float> cam_f;
   DCamera<double> cam_d;
   DeviceBuffer partial, film, counters, rays, hits, post_in, post_out, bdpt_store;
+  DeviceBuffer ph_lights, ph_targets, ph_out, ph_nodes, ph_data;   // PathPhoton: photon pass plan, its raw output, the kd-tree
   WavefrontPool wf;         // wavefront-pipeline queues, allocated on first use
 };
+
+// PathPhoton: the caustic photon pass (ref: engine/renderer.cpp:344-372, engine/photon_integrator.hpp:93-137) — plan the
+// photons per emissive sphere on the host, trace them on the GPU, build the kd-tree on the host as PhotonMap::build does
+// (ref: engine/photon_map.hpp:104-108, :222-245) and hand it to the render through P.
+namespace {
+struct HostPhoton { double p[3], dir[3], power[3]; int axis; };
+void photon_build_tree(std::vector<HostPhoton>& ph, size_t start, size_t end, int depth) {
+  if (end - start <= 1) return;
+  const int axis = depth % 3;
+  const size_t mid = start + (end - start) / 2;
+  std::nth_element(ph.begin() + start, ph.begin() + mid, ph.begin() + end, [axis](const HostPhoton& a, const HostPhoton& b) { return a.p[axis] < b.p[axis]; });
+  ph[mid].axis = axis;
+  photon_build_tree(ph, start, mid, depth + 1);
+  photon_build_tree(ph, mid + 1, end, depth + 1);
+}
+template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderParams& P, const DScene<R>& sc, size_t lds_bytes, hipStream_t stream) {
+  const double kPi = 3.14159265358979323846;
+  const std::vector<rtx_sphere>& sph = c->scene.h_spheres;
+  const std::vector<rtx_material>& mats = c->scene.h_materials;
+  P.ph_nodes = nullptr; P.ph_data = nullptr; P.n_photons = 0;
+  P.gather_k = s->photon_gather_count; P.gather_radius = (double)s->caustic_gather_radius;
+  std::vector<size_t> lights;
+  double total_power = 0.0;
+  for (size_t i = 0; i < sph.size(); ++i) {
+    const rtx_material& m = mats[sph[i].material_id];
+    if (m.emission[0] > 0 || m.emission[1] > 0 || m.emission[2] > 0) { lights.push_back(i); total_power += (m.emission[0] + m.emission[1] + m.emission[2]) / 3.0; }
+  }
+  std::vector<int32_t> targets;
+  for (size_t i = 0; i < sph.size(); ++i) {
+    const rtx_material& m = mats[sph[i].material_id];
+    if (m.type == RTX_MAT_DIELECTRIC || m.type == RTX_MAT_METAL || m.fuzz < 0.1) targets.push_back((int32_t)i);   // ref: photon_integrator.hpp:110-119
+  }
+  if (lights.empty() || targets.empty()) return RTX_OK;
+  std::vector<DPhotonLight> plan;
+  unsigned long long total = 0;
+  for (size_t li : lights) {
+    const rtx_material& m = mats[sph[li].material_id];
+    const double fraction = ((m.emission[0] + m.emission[1] + m.emission[2]) / 3.0) / total_power;
+    const size_t n = (size_t)((double)s->caustic_photon_count * fraction);
+    if (n == 0) continue;
+    const double area = 4.0 * kPi * sph[li].radius * sph[li].radius;
+    DPhotonLight L;
+    L.sphere = (int32_t)li; L.first = (uint32_t)total; L.count = (uint32_t)n; L.pad = 0;
+    for (int a = 0; a < 3; ++a) L.power[a] = m.emission[a] * (area / (double)n);
+    plan.push_back(L);
+    total += n;
+  }
+  if (total == 0) return RTX_OK;
+  if (total >= 0x7fffffffull) return fail(RTX_ERR_INVALID_ARGUMENT, "caustic_photon_count %llu is too large", (unsigned long long)s->caustic_photon_count);
+  const uint32_t n = (uint32_t)total;
+  if (!c->ph_lights.upload(plan.data(), plan.size() * sizeof(DPhotonLight)) || !c->ph_targets.upload(targets.data(), targets.size() * sizeof(int32_t)) ||
+      !c->ph_out.ensure((size_t)n * 10 * sizeof(R)))
+    return fail(RTX_ERR_OUT_OF_MEMORY, "photon pass buffers (%u photons)", n);
+  launch_photon_trace(sc, P, (const DPhotonLight*)c->ph_lights.ptr, (int)plan.size(), (const int32_t*)c->ph_targets.ptr, (int)targets.size(), n, (R*)c->ph_out.ptr,
+                      (DCounters*)c->counters.ptr, lds_bytes, stream);
+  HIP_TRY(hipGetLastError());
+  std::vector<R> raw((size_t)n * 10);
+  HIP_TRY(hipMemcpyAsync(raw.data(), c->ph_out.ptr, raw.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  std::vector<HostPhoton> ph;
+  for (uint32_t i = 0; i < n; ++i) {   // in emission order, as the reference's push_back sequence
+    if (raw[(size_t)9 * n + i] == R(0)) continue;
+    HostPhoton q;
+    for (int a = 0; a < 3; ++a) { q.p[a] = (double)raw[(size_t)a * n + i]; q.dir[a] = (double)raw[(size_t)(3 + a) * n + i]; q.power[a] = (double)raw[(size_t)(6 + a) * n + i]; }
+    q.axis = 0;
+    ph.push_back(q);
+  }
+  if (ph.empty()) return RTX_OK;
+  photon_build_tree(ph, 0, ph.size(), 0);
+  std::vector<DPhotonNode<R>> nodes(ph.size());
+  std::vector<DPhotonData<R>> data(ph.size());
+  for (size_t i = 0; i < ph.size(); ++i)
+    for (int a = 0; a < 3; ++a) { nodes[i].p[a] = (R)ph[i].p[a]; nodes[i].axis = ph[i].axis; data[i].dir[a] = (R)ph[i].dir[a]; data[i].power[a] = (R)ph[i].power[a]; }
+  if (!c->ph_nodes.upload(nodes.data(), nodes.size() * sizeof(DPhotonNode<R>)) || !c->ph_data.upload(data.data(), data.size() * sizeof(DPhotonData<R>)))
+    return fail(RTX_ERR_OUT_OF_MEMORY, "photon map (%zu photons)", ph.size());
+  P.ph_nodes = c->ph_nodes.ptr; P.ph_data = c->ph_data.ptr; P.n_photons = (int32_t)ph.size();
+  return RTX_OK;
+}
+}  // namespace
+
 
 extern "C" {
 
@@ -105,6 +186,7 @@ int rtx_destroy(rtx_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   c->scene.release();
   c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release(); c->post_in.release(); c->post_out.release(); c->bdpt_store.release();
+  c->ph_lights.release(); c->ph_targets.release(); c->ph_out.release(); c->ph_nodes.release(); c->ph_data.release();
   c->wf.release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -145,6 +227,7 @@ int rtx_get_bvh_info(rtx_ctx* c, rtx_bvh_info* out) {
   return RTX_OK;
 }
 
+
 static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, rtx_stats* stats) {
   if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
   if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "render before upload_scene");
@@ -156,8 +239,11 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   if (s->shard_index < 0 || s->shard_index >= sc_n) return fail(RTX_ERR_INVALID_ARGUMENT, "shard %d of %d", s->shard_index, sc_n);
   if (s->precision != RTX_PRECISION_F32 && s->precision != RTX_PRECISION_F64) return fail(RTX_ERR_INVALID_ARGUMENT, "precision %d", s->precision);
   if (s->pipeline < RTX_PIPELINE_AUTO || s->pipeline > RTX_PIPELINE_WAVEFRONT) return fail(RTX_ERR_INVALID_ARGUMENT, "pipeline %d", s->pipeline);
-  if (s->mode != RTX_MODE_WHITTED && s->mode != RTX_MODE_PATHTRACE && s->mode != RTX_MODE_BDPT)
-    return fail(RTX_ERR_UNSUPPORTED, "render mode %d: only Whitted (0), PathTrace (1) and BDPT (2) are implemented", s->mode);
+  if (s->mode != RTX_MODE_WHITTED && s->mode != RTX_MODE_PATHTRACE && s->mode != RTX_MODE_BDPT && s->mode != RTX_MODE_PATHPHOTON)
+    return fail(RTX_ERR_UNSUPPORTED, "render mode %d: only Whitted (0), PathTrace (1), BDPT (2) and PathPhoton (6) are implemented", s->mode);
+  if (s->mode == RTX_MODE_PATHPHOTON && (s->photon_gather_count < 1 || s->photon_gather_count > kPhotonMaxGather))
+    return fail(RTX_ERR_UNSUPPORTED, "photon_gather_count %d: 1 to %d are implemented", s->photon_gather_count, kPhotonMaxGather);
+  if (s->mode == RTX_MODE_PATHPHOTON && !(s->caustic_gather_radius >= 0.0f)) return fail(RTX_ERR_INVALID_ARGUMENT, "caustic_gather_radius %g", (double)s->caustic_gather_radius);
   if (s->mode == RTX_MODE_BDPT && !(s->clamp_max == s->clamp_max)) return fail(RTX_ERR_INVALID_ARGUMENT, "clamp_max is NaN");
   if (s->rng < RTX_RNG_AUTO || s->rng > RTX_RNG_PCG4D) return fail(RTX_ERR_INVALID_ARGUMENT, "rng %d", s->rng);
   if (!host_out && !dev_out) return fail(RTX_ERR_INVALID_ARGUMENT, "output buffer is NULL");
@@ -189,14 +275,16 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   // tolerances leave no room for single precision): a single-precision request is promoted.
   const bool whitted = s->mode == RTX_MODE_WHITTED;
   const bool bdpt = s->mode == RTX_MODE_BDPT;
-  const bool mnee = !whitted && !bdpt && s->use_mnee != 0 && s->use_nee != 0;
+  const bool photon = s->mode == RTX_MODE_PATHPHOTON;
+  const bool mnee = !whitted && !bdpt && !photon && s->use_mnee != 0 && s->use_nee != 0;
   const bool f64 = s->precision == RTX_PRECISION_F64 || mnee;
   const bool f64_req = f64;
   // AUTO: scenes that walk a tree run the queue-based pipeline (its traversal kernels hold 2-4x
   // the waves of the fused kernel, measured 1.6x faster on a 10 M-triangle scene); scenes small
   // enough for the linear / flat intersection stay fused (no queue traffic, measured 2-3x faster).
   int pipeline = s->pipeline;
-  if (pipeline == RTX_PIPELINE_AUTO) pipeline = (!f64_req && !whitted && !bdpt && c->scene.n_prims > kLinearMaxPrims) ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED;
+  if (pipeline == RTX_PIPELINE_AUTO) pipeline = (!f64_req && !whitted && !bdpt && !photon && c->scene.n_prims > kLinearMaxPrims) ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED;
+  if (pipeline == RTX_PIPELINE_WAVEFRONT && photon) return fail(RTX_ERR_UNSUPPORTED, "the PathPhoton mode is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && bdpt) return fail(RTX_ERR_UNSUPPORTED, "the BDPT mode is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && whitted) return fail(RTX_ERR_UNSUPPORTED, "the Whitted mode is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && mnee) return fail(RTX_ERR_UNSUPPORTED, "use_mnee is implemented by the fused pipeline only");
@@ -218,9 +306,9 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     if (items >= 0x7fffffffull) return fail(RTX_ERR_INVALID_ARGUMENT, "film too large for one launch (%llu work items)", items);
     if (!c->partial.ensure((size_t)items * 3 * elem)) return fail(RTX_ERR_OUT_OF_MEMORY, "chunk-sum buffer (%llu bytes)", (unsigned long long)(items * 3 * elem));
     FusedLaunch L;
-    L.mode = whitted ? MODE_TREE_UV : c->scene.fused_mode(f64);
+    L.mode = (whitted || photon) ? MODE_TREE_UV : c->scene.fused_mode(f64);
     if (bdpt && L.mode == MODE_TREE) L.mode = MODE_TREE_UV;
-    L.integ = whitted ? INTEG_WHITTED : bdpt ? INTEG_BDPT : mnee ? INTEG_PATH_MNEE : INTEG_PATH;
+    L.integ = whitted ? INTEG_WHITTED : bdpt ? INTEG_BDPT : photon ? INTEG_PATHPHOTON : mnee ? INTEG_PATH_MNEE : INTEG_PATH;
     const size_t mat_bytes = (size_t)c->scene.dev_f.n_mats * (f64 ? sizeof(DMaterial<double>) : sizeof(DMaterial<float>));
     L.lds_mats = mat_bytes <= kMaxLdsMaterialBytes;
     if (!L.lds_mats) L.mode = MODE_TREE_UV;
@@ -231,6 +319,11 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     const int blocks_per_cu = stack ? 3 : 6;
     L.grid = (int)std::min<unsigned long long>((items + kBlock - 1) / kBlock, (unsigned long long)c->n_cus * blocks_per_cu);
     int lrc;
+    if (photon) {   // the photon pass comes first (ref: engine/renderer.cpp:344-372); its rays are counted as closest-hit queries
+      const size_t walk_lds = stack ? (size_t)kStackDepth * kBlock * sizeof(int) : 0;
+      const int prc = f64 ? photon_pass(c, s, P, c->scene.dev_d, walk_lds, stream) : photon_pass(c, s, P, c->scene.dev_f, walk_lds, stream);
+      if (prc != RTX_OK) return prc;
+    }
     if (bdpt) {
       // every lane keeps the connectible vertices of its light subpath (at most max_depth + 1) in global memory;
       // the grid shrinks when that would pass 2 GiB

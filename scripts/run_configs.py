@@ -16,6 +16,7 @@ CONFIGS = {
     "c3": [("cornell_box_quad", dict(width=800, height=800, samples_per_pixel=128, max_depth=50)),
            ("caustics_test", dict(width=800, height=800, samples_per_pixel=128, max_depth=16))],
     "c3bdpt": [("caustics_test", dict(width=800, height=800, samples_per_pixel=128, max_depth=16, mode=2))],   # the scene file's own mode: BDPT
+    "c2photon": [("cornell_box", dict(width=1920, height=1080, samples_per_pixel=16, max_depth=500, mode=6))],   # PathPhoton with the reference's defaults (50000 photons, 100 gathered, radius 0.1)
     "c4env": [("environment_demo", dict(width=3840, height=2160, samples_per_pixel=256))],
     "c4": [("environment_demo", dict(width=3840, height=2160, samples_per_pixel=4096)),
            ("earth_demo", dict(width=3840, height=2160, samples_per_pixel=4096))],

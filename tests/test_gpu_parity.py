@@ -223,6 +223,44 @@ def test_bdpt_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
         pt.render()
 
 
+@pytest.mark.parametrize("name,nee,photons,k,radius", [("cornell_box", 1, 4000, 40, 0.3), ("cornell_box", 0, 1500, 10, 0.1), ("kitchen_points", 1, 3000, 25, 0.25),
+                                                        ("textured", 1, 3000, 100, 0.5), ("normal_mapped", 1, 3000, 30, 0.3), ("cornell_box_quad", 1, 2000, 20, 0.2)])
+def test_pathphoton_film_equals_oracle(name, nee, photons, k, radius, pkg, oracle, tracer, load_scene):
+    """RenderMode::PathPhoton (engine/renderer.cpp:344-372 photon pass, :844-976 integrator): the GPU traces the caustic photons
+    (one lane each, counter-based numbers), the host builds the reference's kd-tree over them, the render gathers the k nearest
+    at every Lambertian vertex.  Double precision agrees with the oracle run on the same numbers (the oracle equals the real
+    reference bit for bit on 5 seeded films); single precision traces slightly different photons, so it is held to the image mean.
+    cornell_box_quad has no emissive sphere: no photons, the mode degenerates to its plain path tracer."""
+    sd = load_scene(name)
+    W, H, spp = 40, 24, 4
+    over = dict(width=W, height=H, samples_per_pixel=spp, max_depth=min(sd.max_depth, 10), seed=83, use_nee=nee, mode=pkg.abi.MODE_PATHPHOTON,
+                caustic_photon_count=photons, photon_gather_count=k, caustic_gather_radius=radius)
+    ref, ost = oracle.OracleScene(sd).render(sd.camera(W, H), sd.settings(**over), oracle.RNG_COUNTER, threads=16)
+    pt = tracer(sd)
+    pt.set_camera(sd.camera(W, H))
+    pt.set_settings(sd.settings(precision=pkg.abi.PRECISION_F64, **over))
+    got = pt.render().astype(np.float64)
+    st = pt.last_stats
+    loose = name == "kitchen_points"   # checker floor in the plane y = 0 (see test_f64_film_equals_oracle)
+    assert st.samples == W * H * spp and st.pipeline_used == pkg.abi.PIPELINE_FUSED and st.precision_used == pkg.abi.PRECISION_F64
+    if not loose:
+        assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow and st.segments == ost.segments
+    bad = (np.abs(got - ref) > 1e-5 * (1.0 + np.abs(ref))).any(axis=2)
+    assert bad.mean() < (0.03 if loose else 0.005), (bad.mean(), np.abs(got - ref).max())
+    assert abs(got.mean() - ref.mean()) < (3e-3 if loose else 2e-4) * (1 + ref.mean())
+    if name != "cornell_box_quad":   # the photons do contribute
+        plain, _ = oracle.OracleScene(sd).render(sd.camera(W, H), sd.settings(**dict(over, caustic_photon_count=0)), oracle.RNG_COUNTER, threads=16)
+        assert np.abs(ref - plain).max() > 1e-3
+    ref32, _ = oracle.OracleScene(sd).render(sd.camera(W, H), sd.settings(**over), oracle.RNG_COUNTER_PCG, threads=16)
+    pt.set_settings(sd.settings(precision=pkg.abi.PRECISION_F32, **over))
+    f32 = pt.render().astype(np.float64)
+    assert pt.last_stats.precision_used == pkg.abi.PRECISION_F32 and pt.last_stats.samples == W * H * spp
+    assert abs(f32.mean() - ref32.mean()) < 0.05 * (1 + ref32.mean()), (f32.mean(), ref32.mean())
+    pt.set_settings(sd.settings(photon_gather_count=129, **{k_: v for k_, v in over.items() if k_ != "photon_gather_count"}))
+    with pytest.raises(pkg.abi.RtxError, match="photon_gather_count"):
+        pt.render()
+
+
 @pytest.mark.parametrize("name,mis", [("cornell_box", 1), ("cornell_box", 0), ("cornell_box_quad", 1), ("caustics_test", 1), ("kitchen_sink", 0), ("disk_room", 1), ("normal_mapped", 1)])
 def test_mnee_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
     """use_mnee = 1 (the reference's CLI default; MNEE::evaluate, engine/spectral/mnee.hpp:632-763): the render is
