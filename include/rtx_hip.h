@@ -108,7 +108,8 @@ enum { RTX_PIPELINE_AUTO = 0, RTX_PIPELINE_FUSED = 1, RTX_PIPELINE_WAVEFRONT = 2
 /* RenderMode (engine/renderer.hpp:26-34), the modes this backend implements, with the reference's values:
  * Whitted = Renderer::ray_color_whitted (engine/renderer.cpp:483-569), PathTrace = ray_color_path (:580-841),
  * BDPT = BDPTIntegrator::Li (engine/bdpt.cpp:71-128; max_eye_depth = max_light_depth = max_depth as in
- * engine/renderer.cpp:304-313).  Any other value returns RTX_ERR_UNSUPPORTED. */
+ * engine/renderer.cpp:304-313), PathPhoton = the caustic photon pass (engine/renderer.cpp:344-372, engine/photon_integrator.hpp:93-293)
+ * followed by Renderer::ray_color_path_with_caustics (engine/renderer.cpp:844-976).  Any other value returns RTX_ERR_UNSUPPORTED. */
 enum { RTX_MODE_WHITTED = 0, RTX_MODE_PATHTRACE = 1, RTX_MODE_BDPT = 2, RTX_MODE_PATHPHOTON = 6 };
 /* Counter-based generator behind the samples (the reference's per-thread mt19937 has no parallel counterpart):
  * AUTO = PCG4D for single precision, PHILOX for double; PHILOX = Philox-4x32-10 (Random123), the generator the

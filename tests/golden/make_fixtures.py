@@ -255,6 +255,22 @@ def make_pathphoton_fixtures():
         print("film", tag, float(film.mean()), info)
 
 
+def make_pathphoton_converged():
+    """PathPhoton films of the real reference at 4N spp plus two N-spp films of other seeds.  Every run traces its own photon
+    map (other aim seed), so the noise floor holds the map's variance too."""
+    for n, depth, photons, k, radius in (("cornell_box", 12, 3000, 30, 0.3),):
+        W, H, N = 64, 36, 128
+        extra = [photons, k, repr(radius)]
+        hi, secs = ref_film(n, W, H, 4 * N, depth, 1001, threads=8, mode=6, extra=extra)
+        lo_a, _ = ref_film(n, W, H, N, depth, 2002, threads=8, mode=6, extra=extra)
+        lo_b, _ = ref_film(n, W, H, N, depth, 3003, threads=8, mode=6, extra=extra)
+        floor = max(rel_mse(lo_a, hi), rel_mse(lo_b, hi))
+        np.savez_compressed(os.path.join(HERE, "converged", n + "_pathphoton.npz"), film=hi.astype(np.float32), W=W, H=H, N=N, depth=depth, mode=6,
+                            caustic_photon_count=photons, photon_gather_count=k, caustic_gather_radius=np.float32(radius),
+                            noise_floor_relmse=floor, ref_msamples_per_s_8threads=W * H * 4 * N / secs * 1e-6)
+        print("converged pathphoton", n, "floor", floor, "ref Msamples/s", W * H * 4 * N / secs * 1e-6)
+
+
 def make_bdpt_converged():
     """BDPT films of the real reference at 4N spp plus two N-spp films of other seeds (the Monte-Carlo noise floor)."""
     for n, depth in (("caustics_test", 16), ("cornell_box_quad", 12)):
@@ -286,6 +302,10 @@ def main():
         return
     if "--pathphoton-only" in sys.argv:
         make_pathphoton_fixtures()
+        make_pathphoton_converged()
+        return
+    if "--pathphoton-converged-only" in sys.argv:
+        make_pathphoton_converged()
         return
     if "--bdpt-only" in sys.argv:
         make_bdpt_fixtures()
@@ -356,6 +376,7 @@ def main():
         print("converged", n, "floor", floor, "ref Msamples/s", W * H * 4 * N / secs * 1e-6)
 
     make_bdpt_converged()
+    make_pathphoton_converged()
 
     # --- scalar known answers ---------------------------------------------------------------
     for n in ("kitchen_sink", "environment_demo", "cornell_box", "textured", "disk_room"):
