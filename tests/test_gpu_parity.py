@@ -526,7 +526,7 @@ def test_corner_sizes_all_modes(name, pkg, tracer, load_scene):
     n = 0
     for (W, H, spp, depth) in SIZES:
         pt.set_camera(sd.camera(W, H))
-        for mode in (abi.MODE_WHITTED, abi.MODE_PATHTRACE, abi.MODE_BDPT):
+        for mode in (abi.MODE_WHITTED, abi.MODE_PATHTRACE, abi.MODE_BDPT, abi.MODE_PATHPHOTON):
             for pipe in (abi.PIPELINE_FUSED, abi.PIPELINE_WAVEFRONT):
                 for prec in (abi.PRECISION_F32, abi.PRECISION_F64):
                     if pipe == abi.PIPELINE_WAVEFRONT and (mode != abi.MODE_PATHTRACE or prec == abi.PRECISION_F64):
@@ -538,4 +538,4 @@ def test_corner_sizes_all_modes(name, pkg, tracer, load_scene):
                     if depth == 0:
                         assert float(np.abs(film).max()) == 0.0 or mode == abi.MODE_WHITTED   # no bounce allowed: black
                     n += 1
-    assert n == 6 * 7
+    assert n == 6 * 9
