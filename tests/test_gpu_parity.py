@@ -325,14 +325,18 @@ def test_f32_film_within_tolerance_of_reference(name, pkg, tracer, load_scene):
     assert np.all(np.abs(mg - mr) / mr < (0.2 if extra else 0.015)), (mg, mr)
 
 
-def test_render_is_reproducible_and_shard_invariant(pkg, tracer, load_scene):
+@pytest.mark.parametrize("mode", ["pathtrace", "whitted", "bdpt", "pathphoton"])
+def test_render_is_reproducible_and_shard_invariant(mode, pkg, tracer, load_scene):
     """Counter-based sampling keyed on the absolute pixel: same seed => same film, bit for bit;
-    the union of row shards (any count) equals the unsharded film, bit for bit."""
-    sd = load_scene("cornell_box")
+    the union of row shards (any count) equals the unsharded film, bit for bit — in every render mode (every shard of a
+    PathPhoton render traces the same photon map)."""
+    sd = load_scene("kitchen_points" if mode == "whitted" else "cornell_box")   # Whitted lights from point lights only
     W, H = 96, 54
     pt = tracer(sd)
     pt.set_camera(sd.camera(W, H))
-    base = dict(width=W, height=H, samples_per_pixel=24, max_depth=30, seed=9)
+    extra = {"pathtrace": {}, "whitted": dict(mode=pkg.abi.MODE_WHITTED), "bdpt": dict(mode=pkg.abi.MODE_BDPT),
+             "pathphoton": dict(mode=pkg.abi.MODE_PATHPHOTON, caustic_photon_count=5000, photon_gather_count=20, caustic_gather_radius=0.2)}[mode]
+    base = dict(width=W, height=H, samples_per_pixel=24 if mode == "pathtrace" else 6, max_depth=30 if mode == "pathtrace" else 10, seed=9, **extra)
     pt.set_settings(sd.settings(**base))
     a = pt.render().copy()
     b = pt.render().copy()
