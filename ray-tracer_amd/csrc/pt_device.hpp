@@ -1345,7 +1345,8 @@ RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMateria
   Hit<R> rec;
   const bool hit = trace_closest<R, MODE>(sc, ps.ray, R(0.001), R(1e9), rec, st);
   if constexpr (INTEG == INTEG_PATHPHOTON) {
-    return photon_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<R>& sr, R t_max) { return trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st); });
+    static_assert(INTEG != INTEG_PATHPHOTON, "PathPhoton vertices are stepped by the kernel itself: the density estimate is a wave-wide operation");
+    return 0u;
   } else if constexpr (INTEG == INTEG_WHITTED) {
     return whitted_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<R>& sr, R t_max) { return trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st); }, extra_shadow);
   } else {

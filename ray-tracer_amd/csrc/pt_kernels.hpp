@@ -118,25 +118,68 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? ((LEAN & 1) ? RTX_LEAN
   bool active = fetch();
   if (active) { key.sample = (uint32_t)s++; path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key); }
   w_samples += (uint32_t)__popcll(__ballot(active));
-  while (active) {
-    w_steps += (uint32_t)__popcll(__ballot(1));
-    const uint32_t did = path_step<R, MODE, INTEG, MODE == MODE_TREE_UV && (LEAN & 32) == 0>(ps, sc, mats, P, key, st, extra_traces, extra_shadow);
-    w_shadow += (uint32_t)__popcll(__ballot((did & STEP_SHADOW) != 0));
-    w_shaded += (uint32_t)__popcll(__ballot((did & STEP_SHADED) != 0));
-    bool started = false;
-    if (!(ps.bounce_flags & F_ALIVE)) {
-      sum = sum + ps.acc;
-      if (s == s_end) {
-        R* o = partial + (size_t)cur * 3u;
-        o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
-        active = fetch();
-        if (!active) break;
+  if constexpr (INTEG == INTEG_PATHPHOTON) {
+    // The density estimate is computed by the whole wave (pt_photon_wave.hpp), so every lane stays in the loop until the
+    // wave has no path left; a lane without a path skips the vertex and helps with the estimates of the others.
+    __shared__ R cand_d2[kBlock / 64][kPhotonCand];
+    __shared__ int cand_id[kBlock / 64][kPhotonCand];
+    __shared__ DPhotonNode<R> tree_top[kPhotonTop];
+    photon_stage_top<R>(P, tree_top);
+    __syncthreads();
+    const PhotonCand<R> pc = {cand_d2[threadIdx.x >> 6], cand_id[threadIdx.x >> 6], tree_top};
+    for (;;) {
+      bool want = false;
+      V3<R> g_pos = {R(0), R(0), R(0)}, g_n = g_pos, g_w = g_pos;
+      uint32_t did = 0u;
+      if (active) {
+        Hit<R> rec;
+        const bool hit = trace_closest<R, MODE>(sc, ps.ray, R(0.001), R(1e9), rec, st);
+        did = photon_vertex(
+            ps, hit, rec, sc, mats, P, key, [&](const Ray<R>& sr, R t_max) { return trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st); },
+            [&](V3<R> pos, V3<R> n, V3<R> w) { want = true; g_pos = pos; g_n = n; g_w = w; });
       }
-      key.sample = (uint32_t)s++;
-      path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key);
-      started = true;
+      w_steps += (uint32_t)__popcll(__ballot(active));
+      w_shadow += (uint32_t)__popcll(__ballot((did & STEP_SHADOW) != 0));
+      w_shaded += (uint32_t)__popcll(__ballot((did & STEP_SHADED) != 0));
+      photon_gather_wave<R>(P, want, g_pos, g_n, g_w, ps.acc, pc);
+      bool started = false;
+      if (active && !(ps.bounce_flags & F_ALIVE)) {
+        sum = sum + ps.acc;
+        if (s == s_end) {
+          R* o = partial + (size_t)cur * 3u;
+          o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+          active = fetch();
+        }
+        if (active) {
+          key.sample = (uint32_t)s++;
+          path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key);
+          started = true;
+        }
+      }
+      w_samples += (uint32_t)__popcll(__ballot(started));
+      if (!__any(active)) break;
     }
-    w_samples += (uint32_t)__popcll(__ballot(started));   // outside the divergent branch: counters must be added in uniform flow
+  } else {
+    while (active) {
+      w_steps += (uint32_t)__popcll(__ballot(1));
+      const uint32_t did = path_step<R, MODE, INTEG, MODE == MODE_TREE_UV && (LEAN & 32) == 0>(ps, sc, mats, P, key, st, extra_traces, extra_shadow);
+      w_shadow += (uint32_t)__popcll(__ballot((did & STEP_SHADOW) != 0));
+      w_shaded += (uint32_t)__popcll(__ballot((did & STEP_SHADED) != 0));
+      bool started = false;
+      if (!(ps.bounce_flags & F_ALIVE)) {
+        sum = sum + ps.acc;
+        if (s == s_end) {
+          R* o = partial + (size_t)cur * 3u;
+          o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+          active = fetch();
+          if (!active) break;
+        }
+        key.sample = (uint32_t)s++;
+        path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key);
+        started = true;
+      }
+      w_samples += (uint32_t)__popcll(__ballot(started));   // outside the divergent branch: counters must be added in uniform flow
+    }
   }
   w_samples = wave_max(w_samples); w_steps = wave_max(w_steps); w_shadow = wave_max(w_shadow); w_shaded = wave_max(w_shaded);
   if constexpr (INTEG != INTEG_PATH) {
