@@ -62,7 +62,7 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #define RTX_TREE_MIN_WAVES 3   // single-precision tree-walking instances: they sit at the 168-VGPR edge of 3 waves per SIMD
 #endif
 #ifndef RTX_PHOTON_MIN_WAVES
-#define RTX_PHOTON_MIN_WAVES 3   // single-precision PathPhoton instance (its k-nearest arrays live in scratch memory)
+#define RTX_PHOTON_MIN_WAVES 3   // single-precision PathPhoton instance (measured: 4 waves per SIMD spill and are slower)
 #endif
 #ifndef RTX_MNEE_MIN_WAVES
 #define RTX_MNEE_MIN_WAVES 3   // manifold NEE instance (double precision): measured 1: 330 ms, 2: 240, 3: 219, 4: 263 (cornell_box_quad 800x800x16)

@@ -24,6 +24,16 @@ constexpr int kPhotonCand = 256;   // candidate list entries per wave: a multipl
 static_assert(kPhotonCand % 64 == 0 && kPhotonCand >= kPhotonMaxGather + 64, "candidate list too small");
 constexpr int kPhotonCandPerLane = kPhotonCand / 64;
 
+#ifndef RTX_PHOTON_BUCKET
+#define RTX_PHOTON_BUCKET 1024   // measured on the 1080p Cornell box, 50 000 photons: 64: 896 ms, 256: 645, 512: 529, 1024: 470, 2048: 494
+#endif
+constexpr int kPhotonBucket = RTX_PHOTON_BUCKET;   // a subtree of at most this many photons is tested without walking it
+
+#ifndef RTX_PHOTON_UNROLL
+#define RTX_PHOTON_UNROLL 8
+#endif
+constexpr int kPhotonUnroll = RTX_PHOTON_UNROLL;
+
 constexpr int kPhotonTopLevels = 10;   // levels of the kd-tree copied into LDS (a walk step there costs an LDS read, not a trip to L2)
 constexpr int kPhotonTop = 1 << kPhotonTopLevels;
 
@@ -146,22 +156,28 @@ template <class R> RTX_DEV V3<R> photon_query(const DRenderParams& P, const V3<R
       ++level;
       continue;
     }
-    if (end - start <= 64) {   // the whole subtree at once, one photon per lane
-      const int i = start + lane;
-      const bool in = i < end;
-      const DPhotonNode<R> q = nodes[in ? i : start];
-      const R d2 = len2(V3<R>{q.p[0], q.p[1], q.p[2]} - pos);
-      bool take = in && d2 < bound;
-      unsigned long long m = __ballot(take);
-      if (m != 0ull) {
-        if (n + (int)__popcll(m) > kPhotonCand) {   // n > kPhotonCand - 64 >= k
-          bound = photon_select(pc, n, k, lane);
-          take = take && d2 < bound;
-          m = __ballot(take);
+    if (end - start <= kPhotonBucket) {   // the whole subtree at once, 64 photons per step, one per lane
+      for (int first = start; first < end; first += 64 * kPhotonUnroll) {   // the loads of kPhotonUnroll steps are issued together
+        DPhotonNode<R> q[kPhotonUnroll];
+#pragma unroll
+        for (int j = 0; j < kPhotonUnroll; ++j) { const int i = first + 64 * j + lane; q[j] = nodes[i < end ? i : first]; }
+#pragma unroll
+        for (int j = 0; j < kPhotonUnroll; ++j) {
+          const int i = first + 64 * j + lane;
+          const R d2 = len2(V3<R>{q[j].p[0], q[j].p[1], q[j].p[2]} - pos);
+          bool take = i < end && d2 < bound;
+          unsigned long long m = __ballot(take);
+          if (m != 0ull) {
+            if (n + (int)__popcll(m) > kPhotonCand) {   // n > kPhotonCand - 64 >= k
+              bound = photon_select(pc, n, k, lane);
+              take = take && d2 < bound;
+              m = __ballot(take);
+            }
+            if (take) { const int slot = n + lanes_below(m); pc.d2[slot] = d2; pc.id[slot] = i; }
+            n += (int)__popcll(m);
+            if (n > k && n >= select_at) bound = photon_select(pc, n, k, lane);
+          }
         }
-        if (take) { const int slot = n + lanes_below(m); pc.d2[slot] = d2; pc.id[slot] = i; }
-        n += (int)__popcll(m);
-        if (n > k && n >= select_at) bound = photon_select(pc, n, k, lane);
       }
       start = end;
       continue;
