@@ -110,7 +110,7 @@ struct DRenderParams {
 };
 
 // PathPhoton (pt_photon.hpp)
-constexpr int kPhotonMaxGather = 128;   // largest photon_gather_count the estimate keeps per lane
+constexpr int kPhotonMaxGather = 128;   // largest photon_gather_count the density estimate supports
 struct DPhotonLight { int32_t sphere; uint32_t first, count; int32_t pad; double power[3]; };   // photons [first, first + count) leave this emissive sphere
 template <class R> struct DPhotonNode { R p[3]; int32_t axis; };       // kd-tree in the reference's implicit layout: the median of a range sits at its middle
 template <class R> struct DPhotonData { R dir[3]; R power[3]; };

@@ -56,13 +56,13 @@ def load_scene(pkg):
     return _load
 
 
-def soup_scene(pkg, load_scene_fn):
-    """cornell_box_quad + the 4000-triangle soup the hits/soup.npz fixture was made with."""
+def soup_scene(pkg, load_scene_fn, base="cornell_box_quad", n=4000):
+    """cornell_box_quad + the 4000-triangle soup the hits/soup.npz fixture was made with (or another base / size)."""
     import copy
-    base = load_scene_fn("cornell_box_quad")
+    base = load_scene_fn(base)
     sd = copy.copy(base)
     sd._keep = []
-    soup = pkg.synthetic.triangle_soup(4000, seed=7, extent=2.2, size=0.25, n_materials=5)
+    soup = pkg.synthetic.triangle_soup(n, seed=7, extent=2.2, size=0.25, n_materials=5)
     for k in ("v0", "v1", "v2"):
         soup[k] += (0, 2.5, -2.5)
     sd.triangle_array = soup
