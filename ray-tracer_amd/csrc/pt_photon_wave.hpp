@@ -5,7 +5,9 @@
 // different index in every lane; measured on the 1080p Cornell box that search was 98 % of the render.  Here the 64 lanes
 // of a wave serve the wave's shading points one after the other:
 //  * the kd-tree walk is the same in every lane (scalar state: the range, and two bit masks instead of a stack, see
-//    photon_query); a range of at most 64 photons is tested in one step, one photon per lane, read with one coalesced load;
+//    photon_query) and stops at subtrees of DRenderParams::ph_bucket photons (by default 64^3: maps below that size are
+//    not walked at all); a subtree is searched through bounding boxes of its runs of 64 photons, one box or one photon per
+//    lane, read with coalesced loads (photon_scan);
 //  * photons nearer than the current bound are appended to a candidate list in LDS (kPhotonCand entries per wave); when
 //    the list runs full, and once at the end, the k nearest are selected from it by a bit-wise search for the k-th
 //    smallest distance (the order of non-negative IEEE numbers is the order of their bit patterns), counted with ballots;
@@ -24,13 +26,8 @@ constexpr int kPhotonCand = 256;   // candidate list entries per wave: a multipl
 static_assert(kPhotonCand % 64 == 0 && kPhotonCand >= kPhotonMaxGather + 64, "candidate list too small");
 constexpr int kPhotonCandPerLane = kPhotonCand / 64;
 
-#ifndef RTX_PHOTON_BUCKET
-#define RTX_PHOTON_BUCKET 1024   // measured on the 1080p Cornell box, 50 000 photons: 64: 896 ms, 256: 645, 512: 529, 1024: 470, 2048: 494
-#endif
-constexpr int kPhotonBucket = RTX_PHOTON_BUCKET;   // a subtree of at most this many photons is tested without walking it
-
 #ifndef RTX_PHOTON_UNROLL
-#define RTX_PHOTON_UNROLL 8
+#define RTX_PHOTON_UNROLL 2   // measured on the 1080p Cornell box, 50 000 photons: 8: 156 ms, 4: 147, 2: 144
 #endif
 constexpr int kPhotonUnroll = RTX_PHOTON_UNROLL;
 
@@ -68,6 +65,14 @@ RTX_DEV double lane_value(double v, int src) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 RTX_DEV int lanes_below(unsigned long long mask) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
+
+// Squared distance from `pos` to a box, scaled down a little: never above the distance of a photon inside, rounding included.
+template <class R> RTX_DEV R box_distance2(const DPhotonBox<R> bx, const V3<R> pos) {
+  const R dx = max_(max_(bx.lo[0] - pos.x, pos.x - bx.hi[0]), R(0));
+  const R dy = max_(max_(bx.lo[1] - pos.y, pos.y - bx.hi[1]), R(0));
+  const R dz = max_(max_(bx.lo[2] - pos.z, pos.z - bx.hi[2]), R(0));
+  return (dx * dx + dy * dy + dz * dz) * R(0.9999);
+}
 
 // Cuts the candidate list (n > k entries) down to its k nearest and returns the k-th smallest distance.
 template <class R> RTX_DEV R photon_select(PhotonCand<R> pc, int& n, const int k, const int lane) {
@@ -112,6 +117,70 @@ template <class R> RTX_DEV R photon_select(PhotonCand<R> pc, int& n, const int k
   return key_dist(kth);
 }
 
+// Photons [start, end) of the tree's array (a subtree), searched without walking it: neighbours in the array are neighbours
+// in space, so the host keeps the box of every run of 64 photons and of every group of 64 runs.  One lane tests one group
+// box, then one run box of a group in reach, then one photon of a run in reach.  Adds to the candidate list (n entries) and
+// tightens `bound`.
+template <class R> RTX_DEV void photon_scan(const DRenderParams& P, const V3<R> pos, const int start, const int end, PhotonCand<R> pc, int& n, R& bound, const int lane) {
+  const DPhotonNode<R>* nodes = (const DPhotonNode<R>*)P.ph_nodes;
+  const DPhotonBox<R>* boxes = (const DPhotonBox<R>*)P.ph_boxes;     // box r: photons [64 r, 64 r + 64)
+  const DPhotonBox<R>* groups = boxes + (P.n_photons + 63) / 64;      // box g: runs [64 g, 64 g + 64)
+  const int k = P.gather_k;
+  const int select_at = (kPhotonCand - 64 < k + 64) ? kPhotonCand - 64 : k + 64;   // list length that triggers a selection (> k)
+  const int run0 = start >> 6, run1 = (end - 1) >> 6;
+  for (int gb = run0 >> 6; gb <= run1 >> 6; gb += 64) {
+    R group_d2 = bound;
+    if (gb + lane <= run1 >> 6) group_d2 = box_distance2(groups[gb + lane], pos);
+    unsigned long long todo = __ballot(group_d2 < bound);
+    while (todo != 0ull) {
+      const int gl = (int)__ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      if (!(lane_value(group_d2, gl) < bound)) continue;   // the bound may have tightened since the box was tested
+      const int rb = (gb + gl) * 64;
+      R run_d2 = bound;
+      if (rb + lane >= run0 && rb + lane <= run1) run_d2 = box_distance2(boxes[rb + lane], pos);
+      unsigned long long runs = __ballot(run_d2 < bound);
+      while (runs != 0ull) {   // kPhotonUnroll runs per trip: their loads are issued together
+        int first[kPhotonUnroll];
+        R reach[kPhotonUnroll];
+        DPhotonNode<R> q[kPhotonUnroll];
+#pragma unroll
+        for (int j = 0; j < kPhotonUnroll; ++j) {
+          first[j] = -1; reach[j] = R(0);
+          if (runs != 0ull) {
+            const int l = (int)__ffsll((long long)runs) - 1;
+            runs &= runs - 1ull;
+            first[j] = (rb + l) * 64;
+            reach[j] = lane_value(run_d2, l);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kPhotonUnroll; ++j) {
+          const int i = first[j] + lane;
+          q[j] = nodes[(first[j] >= 0 && i >= start && i < end) ? i : start];
+        }
+#pragma unroll
+        for (int j = 0; j < kPhotonUnroll; ++j) {
+          if (first[j] < 0 || !(reach[j] < bound)) continue;
+          const int i = first[j] + lane;
+          const R d2 = len2(V3<R>{q[j].p[0], q[j].p[1], q[j].p[2]} - pos);
+          bool take = i >= start && i < end && d2 < bound;
+          unsigned long long m = __ballot(take);
+          if (m == 0ull) continue;
+          if (n + (int)__popcll(m) > kPhotonCand) {   // n > kPhotonCand - 64 >= k
+            bound = photon_select(pc, n, k, lane);
+            take = take && d2 < bound;
+            m = __ballot(take);
+          }
+          if (take) { const int slot = n + lanes_below(m); pc.d2[slot] = d2; pc.id[slot] = i; }
+          n += (int)__popcll(m);
+          if (n > k && n >= select_at) bound = photon_select(pc, n, k, lane);
+        }
+      }
+    }
+  }
+}
+
 // One shading point (the same `pos`, `normal` in every lane).  Every lane of the wave must be here.
 // Walk state: the implicit layout of the tree (the median of a range sits at its middle) lets a range be recomputed from
 // the root by replaying the turns taken, so `turns` (bit l = the walk went right at level l) and `pending` (bit l = the
@@ -127,7 +196,6 @@ template <class R> RTX_DEV V3<R> photon_query(const DRenderParams& P, const V3<R
   const int k = P.gather_k;
   const R radius = R(P.gather_radius);
   R bound = radius * radius;   // a photon is a candidate if it is nearer than this
-  const int select_at = (kPhotonCand - 64 < k + 64) ? kPhotonCand - 64 : k + 64;   // list length that triggers a selection (> k)
   int n = 0;
   uint32_t turns = 0u, pending = 0u;
   int level = 0, start = 0, end = P.n_photons;
@@ -156,29 +224,8 @@ template <class R> RTX_DEV V3<R> photon_query(const DRenderParams& P, const V3<R
       ++level;
       continue;
     }
-    if (end - start <= kPhotonBucket) {   // the whole subtree at once, 64 photons per step, one per lane
-      for (int first = start; first < end; first += 64 * kPhotonUnroll) {   // the loads of kPhotonUnroll steps are issued together
-        DPhotonNode<R> q[kPhotonUnroll];
-#pragma unroll
-        for (int j = 0; j < kPhotonUnroll; ++j) { const int i = first + 64 * j + lane; q[j] = nodes[i < end ? i : first]; }
-#pragma unroll
-        for (int j = 0; j < kPhotonUnroll; ++j) {
-          const int i = first + 64 * j + lane;
-          const R d2 = len2(V3<R>{q[j].p[0], q[j].p[1], q[j].p[2]} - pos);
-          bool take = i < end && d2 < bound;
-          unsigned long long m = __ballot(take);
-          if (m != 0ull) {
-            if (n + (int)__popcll(m) > kPhotonCand) {   // n > kPhotonCand - 64 >= k
-              bound = photon_select(pc, n, k, lane);
-              take = take && d2 < bound;
-              m = __ballot(take);
-            }
-            if (take) { const int slot = n + lanes_below(m); pc.d2[slot] = d2; pc.id[slot] = i; }
-            n += (int)__popcll(m);
-            if (n > k && n >= select_at) bound = photon_select(pc, n, k, lane);
-          }
-        }
-      }
+    if (end - start <= P.ph_bucket) {   // no more walking
+      photon_scan<R>(P, pos, start, end, pc, n, bound, lane);
       start = end;
       continue;
     }

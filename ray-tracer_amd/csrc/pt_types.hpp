@@ -103,17 +103,23 @@ struct DRenderParams {
   int32_t rng;                              // RNG_PHILOX / RNG_PCG4D (pt_device.hpp)
   double bg[3], bg_top[3], bg_bottom[3];
   double clamp_max;                         // BDPT: luminance cap per strategy, <= 0 off
-  // PathPhoton: the caustic photon map of this render (pt_photon.hpp), DPhotonNode<R> / DPhotonData<R> arrays
-  const void* ph_nodes; const void* ph_data;
+  // PathPhoton: the caustic photon map of this render (pt_photon.hpp), DPhotonNode<R> / DPhotonData<R> arrays, and the
+  // bounding boxes of its photons (DPhotonBox<R>): one per run of 64 photons, then one per group of 64 runs
+  const void* ph_nodes; const void* ph_data; const void* ph_boxes;
   int32_t n_photons, gather_k;
+  int32_t ph_bucket, ph_pad;                // a kd subtree of at most ph_bucket photons is searched through its boxes, not walked
   double gather_radius;
 };
 
 // PathPhoton (pt_photon.hpp)
+// Default of DRenderParams::ph_bucket: 64 groups of 64 runs of 64 photons.  Measured on the 1080p Cornell box with 50 000 photons
+// (16 spp): walking down to 64 photons 896 ms, 1024: 470, 16384: 235, no walk: 156.
+constexpr int kPhotonBucket = 64 * 64 * 64;
 constexpr int kPhotonMaxGather = 128;   // largest photon_gather_count the density estimate supports
 struct DPhotonLight { int32_t sphere; uint32_t first, count; int32_t pad; double power[3]; };   // photons [first, first + count) leave this emissive sphere
 template <class R> struct DPhotonNode { R p[3]; int32_t axis; };       // kd-tree in the reference's implicit layout: the median of a range sits at its middle
 template <class R> struct DPhotonData { R dir[3]; R power[3]; };
+template <class R> struct DPhotonBox { R lo[3]; R hi[3]; };
 
 struct DCounters { unsigned long long samples, closest, shadow, segments; };
 

@@ -50,7 +50,7 @@ struct rtx_ctx {
   DCamera<float> cam_f;
   DCamera<double> cam_d;
   DeviceBuffer partial, film, counters, rays, hits, post_in, post_out, bdpt_store;
-  DeviceBuffer ph_lights, ph_targets, ph_out, ph_nodes, ph_data;   // PathPhoton: photon pass plan, its raw output, the kd-tree
+  DeviceBuffer ph_lights, ph_targets, ph_out, ph_nodes, ph_data, ph_boxes;   // PathPhoton: photon pass plan, its raw output, the kd-tree
   WavefrontPool wf;         // wavefront-pipeline queues, allocated on first use
 };
 
@@ -72,7 +72,8 @@ template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderPar
   const double kPi = 3.14159265358979323846;
   const std::vector<rtx_sphere>& sph = c->scene.h_spheres;
   const std::vector<rtx_material>& mats = c->scene.h_materials;
-  P.ph_nodes = nullptr; P.ph_data = nullptr; P.n_photons = 0;
+  P.ph_nodes = nullptr; P.ph_data = nullptr; P.ph_boxes = nullptr; P.n_photons = 0; P.ph_bucket = kPhotonBucket; P.ph_pad = 0;
+  if (const char* e = std::getenv("RTX_PHOTON_BUCKET")) { const int v = std::atoi(e); if (v >= 1) P.ph_bucket = v; }   // tests: small maps walk the tree too
   P.gather_k = s->photon_gather_count; P.gather_radius = (double)s->caustic_gather_radius;
   std::vector<size_t> lights;
   double total_power = 0.0;
@@ -126,9 +127,26 @@ template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderPar
   std::vector<DPhotonData<R>> data(ph.size());
   for (size_t i = 0; i < ph.size(); ++i)
     for (int a = 0; a < 3; ++a) { nodes[i].p[a] = (R)ph[i].p[a]; nodes[i].axis = ph[i].axis; data[i].dir[a] = (R)ph[i].dir[a]; data[i].power[a] = (R)ph[i].power[a]; }
-  if (!c->ph_nodes.upload(nodes.data(), nodes.size() * sizeof(DPhotonNode<R>)) || !c->ph_data.upload(data.data(), data.size() * sizeof(DPhotonData<R>)))
+  // Neighbours in the tree's array are neighbours in space: the box of every run of 64 photons lets the search skip the run,
+  // the box of every group of 64 runs (stored after the run boxes) the group.
+  const size_t n_runs = (nodes.size() + 63) / 64, n_groups = (n_runs + 63) / 64;
+  std::vector<DPhotonBox<R>> boxes(n_runs + n_groups);
+  for (size_t b = 0; b < n_runs; ++b) {
+    DPhotonBox<R>& bx = boxes[b];
+    for (int a = 0; a < 3; ++a) bx.lo[a] = bx.hi[a] = nodes[b * 64].p[a];
+    for (size_t i = b * 64; i < std::min(nodes.size(), b * 64 + 64); ++i)
+      for (int a = 0; a < 3; ++a) { bx.lo[a] = std::min(bx.lo[a], nodes[i].p[a]); bx.hi[a] = std::max(bx.hi[a], nodes[i].p[a]); }
+  }
+  for (size_t g = 0; g < n_groups; ++g) {
+    DPhotonBox<R>& bx = boxes[n_runs + g];
+    bx = boxes[g * 64];
+    for (size_t b = g * 64; b < std::min(n_runs, g * 64 + 64); ++b)
+      for (int a = 0; a < 3; ++a) { bx.lo[a] = std::min(bx.lo[a], boxes[b].lo[a]); bx.hi[a] = std::max(bx.hi[a], boxes[b].hi[a]); }
+  }
+  if (!c->ph_nodes.upload(nodes.data(), nodes.size() * sizeof(DPhotonNode<R>)) || !c->ph_data.upload(data.data(), data.size() * sizeof(DPhotonData<R>)) ||
+      !c->ph_boxes.upload(boxes.data(), boxes.size() * sizeof(DPhotonBox<R>)))
     return fail(RTX_ERR_OUT_OF_MEMORY, "photon map (%zu photons)", ph.size());
-  P.ph_nodes = c->ph_nodes.ptr; P.ph_data = c->ph_data.ptr; P.n_photons = (int32_t)ph.size();
+  P.ph_nodes = c->ph_nodes.ptr; P.ph_data = c->ph_data.ptr; P.ph_boxes = c->ph_boxes.ptr; P.n_photons = (int32_t)ph.size();
   return RTX_OK;
 }
 }  // namespace
@@ -186,7 +204,7 @@ int rtx_destroy(rtx_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   c->scene.release();
   c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release(); c->post_in.release(); c->post_out.release(); c->bdpt_store.release();
-  c->ph_lights.release(); c->ph_targets.release(); c->ph_out.release(); c->ph_nodes.release(); c->ph_data.release();
+  c->ph_lights.release(); c->ph_targets.release(); c->ph_out.release(); c->ph_nodes.release(); c->ph_data.release(); c->ph_boxes.release();
   c->wf.release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -227,13 +227,19 @@ def test_bdpt_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
                                                         ("textured", 1, 3000, 100, 0.5), ("normal_mapped", 1, 3000, 30, 0.3), ("cornell_box_quad", 1, 2000, 20, 0.2),
                                                         ("cornell_box", 1, 60000, 50, 0.15),   # enough photons for a kd-tree several levels deep above the GPU's buckets
                                                         ("soup_box", 1, 3000, 30, 0.3)])        # cornell_box + 600 triangles: the instances that walk a BVH with an LDS stack
-def test_pathphoton_film_equals_oracle(name, nee, photons, k, radius, pkg, oracle, tracer, load_scene):
+def test_pathphoton_film_equals_oracle(name, nee, photons, k, radius, pkg, oracle, tracer, load_scene, monkeypatch):
     """RenderMode::PathPhoton (engine/renderer.cpp:344-372 photon pass, :844-976 integrator): the GPU traces the caustic photons
     (one lane each, counter-based numbers), the host builds the reference's kd-tree over them, the render gathers the k nearest
     at every Lambertian vertex.  Double precision agrees with the oracle run on the same numbers (the oracle equals the real
     reference bit for bit on 5 seeded films); single precision traces slightly different photons, so it is held to the image mean.
     cornell_box_quad has no emissive sphere: no photons, the mode degenerates to its plain path tracer."""
     sd = soup_scene(pkg, load_scene, base="cornell_box", n=600) if name == "soup_box" else load_scene(name)
+    # The GPU walks the kd-tree only above subtrees of 64^3 photons and searches those through bounding boxes; the library reads
+    # a smaller subtree size from the environment at every render so that maps of test size are walked too.
+    if photons == 60000:
+        monkeypatch.setenv("RTX_PHOTON_BUCKET", "200")
+    elif photons == 1500:
+        monkeypatch.setenv("RTX_PHOTON_BUCKET", "1")
     W, H, spp = 40, 24, 4
     over = dict(width=W, height=H, samples_per_pixel=spp, max_depth=min(sd.max_depth, 10), seed=83, use_nee=nee, mode=pkg.abi.MODE_PATHPHOTON,
                 caustic_photon_count=photons, photon_gather_count=k, caustic_gather_radius=radius)
