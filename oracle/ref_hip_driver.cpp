@@ -5,8 +5,9 @@
 //        -> ray-tracer_amd/host/reference_adapter.hpp -> C ABI -> MI355X kernels      (film A)
 //        -> the REFERENCE's own Renderer::render on the host cores (use_mnee = false)  (film B)
 //
-//   ref_hip_driver <scene.json> <W> <H> <spp_gpu> <spp_cpu> <depth> <threads> <out_prefix> [cpu_seed [mode]]
-// (mode: RenderMode value, 1 = PathTrace by default, 0 = Whitted, 2 = BDPT; both renderers use it)
+//   ref_hip_driver <scene.json> <W> <H> <spp_gpu> <spp_cpu> <depth> <threads> <out_prefix> [cpu_seed [mode [photons gather_count gather_radius]]]
+// (mode: RenderMode value, 1 = PathTrace by default, 0 = Whitted, 2 = BDPT, 6 = PathPhoton; both renderers use it.
+//  The three photon arguments replace Renderer::Settings' caustic photon defaults.)
 // writes <out_prefix>_gpu.bin (float32) and <out_prefix>_cpu.bin (float64, unclamped) and
 // prints timings.  spp_cpu = 0 skips the CPU render.
 #include <omp.h>
@@ -34,7 +35,9 @@ int main(int argc, char** argv) {
   Renderer::Settings st;
   st.width = W; st.height = H; st.samples_per_pixel = spp_gpu; st.max_depth = depth;
   const int mode = argc > 10 ? atoi(argv[10]) : 1;
-  st.mode = mode == 0 ? RenderMode::Whitted : mode == 2 ? RenderMode::BDPT : RenderMode::PathTrace; st.use_nee = data.use_nee; st.use_mis = data.use_mis; st.use_mnee = false;
+  st.mode = mode == 0 ? RenderMode::Whitted : mode == 2 ? RenderMode::BDPT : mode == 6 ? RenderMode::PathPhoton : RenderMode::PathTrace;
+  if (argc > 13) { st.caustic_photon_count = (size_t)strtoull(argv[11], nullptr, 10); st.photon_gather_count = atoi(argv[12]); st.caustic_gather_radius = (float)atof(argv[13]); }
+  st.use_nee = data.use_nee; st.use_mis = data.use_mis; st.use_mnee = false;
   st.background_color = data.background_color; st.background_top = data.background_top;
   st.background_bottom = data.background_bottom; st.use_background_gradient = data.use_background_gradient;
   Camera cam(data.camera_position, data.camera_target, data.camera_up, data.camera_fov, (double)W / H);

@@ -19,14 +19,15 @@ DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_hip_driver")
 
 @pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/ref_hip_driver not built (needs /root/reference at build time)")
 @pytest.mark.parametrize("name,depth", [("cornell_box", 500), ("cornell_box_quad", 50), ("caustics_test", 16), ("environment_demo", 50),
-                                        ("caustics_test_bdpt", 16), ("cornell_box_quad_bdpt", 12)])
+                                        ("caustics_test_bdpt", 16), ("cornell_box_quad_bdpt", 12), ("cornell_box_pathphoton", 12)])
 def test_reference_loader_feeds_hip_backend_and_matches_reference_renderer(name, depth, tmp_path):
     fx = np.load(os.path.join(GOLDEN, "converged", name + ".npz"))
     W, H, N = int(fx["W"]), int(fx["H"]), int(fx["N"])
     prefix = str(tmp_path / name)
     mode = str(int(fx["mode"])) if "mode" in fx else "1"      # *_bdpt: both renderers in RenderMode::BDPT
-    scene = name[:-5] if name.endswith("_bdpt") else name
-    out = subprocess.run([DRIVER, os.path.join(GOLDEN, "scenes", scene + ".json"), str(W), str(H), str(N), str(N), str(depth), "16", prefix, "99", mode],
+    scene = name[:-5] if name.endswith("_bdpt") else name[:-11] if name.endswith("_pathphoton") else name
+    photon = [str(int(fx["caustic_photon_count"])), str(int(fx["photon_gather_count"])), repr(float(fx["caustic_gather_radius"]))] if "caustic_photon_count" in fx else []
+    out = subprocess.run([DRIVER, os.path.join(GOLDEN, "scenes", scene + ".json"), str(W), str(H), str(N), str(N), str(depth), "16", prefix, "99", mode] + photon,
                          cwd=GOLDEN, check=True, capture_output=True, text=True, timeout=110).stdout
     gpu = np.fromfile(prefix + "_gpu.bin", dtype=np.float32).reshape(H, W, 3).astype(np.float64)
     cpu = np.fromfile(prefix + "_cpu.bin", dtype=np.float64).reshape(H, W, 3)
@@ -36,6 +37,8 @@ def test_reference_loader_feeds_hip_backend_and_matches_reference_renderer(name,
     # than the 1.25 the four-seed average has to meet in test_f32_film_within_tolerance_of_reference
     assert rel_mse(gpu, ref) <= 1.5 * floor, (rel_mse(gpu, ref), floor)
     mg, mc = np.clip(gpu, 0, 1).mean(axis=(0, 1)), np.clip(ref, 0, 1).mean(axis=(0, 1))
-    assert np.all(np.abs(mg - mc) / mc < 0.03), (mg, mc)
+    # PathPhoton: every render has its own photon map (the reference's aim generator is seeded per thread id), whose variance
+    # is part of the means
+    assert np.all(np.abs(mg - mc) / mc < (0.2 if photon else 0.03)), (mg, mc)
     lines = [l for l in out.splitlines() if l.startswith("@@")]
     print(name, *lines)
