@@ -123,10 +123,11 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? ((LEAN & 1) ? RTX_LEAN
     // wave has no path left; a lane without a path skips the vertex and helps with the estimates of the others.
     __shared__ R cand_d2[kBlock / 64][kPhotonCand];
     __shared__ int cand_id[kBlock / 64][kPhotonCand];
-    __shared__ DPhotonNode<R> tree_top[kPhotonTop];
-    photon_stage_top<R>(P, tree_top);
+    __shared__ __align__(16) R photon_table[photon_table_words<R>()];
+    PhotonCand<R> pc;
+    pc.d2 = cand_d2[threadIdx.x >> 6]; pc.id = cand_id[threadIdx.x >> 6];
+    photon_stage_table<R>(P, photon_table, pc);
     __syncthreads();
-    const PhotonCand<R> pc = {cand_d2[threadIdx.x >> 6], cand_id[threadIdx.x >> 6], tree_top};
     for (;;) {
       bool want = false;
       V3<R> g_pos = {R(0), R(0), R(0)}, g_n = g_pos, g_w = g_pos;

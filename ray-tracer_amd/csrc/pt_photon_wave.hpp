@@ -34,22 +34,54 @@ constexpr int kPhotonUnroll = RTX_PHOTON_UNROLL;
 constexpr int kPhotonTopLevels = 10;   // levels of the kd-tree copied into LDS (a walk step there costs an LDS read, not a trip to L2)
 constexpr int kPhotonTop = 1 << kPhotonTopLevels;
 
-// d2, id: this wave's candidate list in LDS.  top: the workgroup's copy of the first kPhotonTopLevels levels of the tree,
-// addressed like a binary heap (root 1, children 2h and 2h + 1).
-template <class R> struct PhotonCand { R* d2; int* id; const DPhotonNode<R>* top; };
+// The workgroup's photon table in LDS holds one of two things, chosen by the size of the map (the same choice in every
+// workgroup): for a map that is walked (more than ph_bucket photons) the first kPhotonTopLevels levels of the kd-tree,
+// addressed like a binary heap (root 1, children 2h and 2h + 1); for a map that is not, its bounding boxes (group boxes, then
+// run boxes) as far as kPhotonLdsBoxes entries hold them all.  Either way the serial steps of a search read LDS, not L2.
+constexpr int kPhotonLdsBoxes = 896;
+template <class R> constexpr int photon_table_words() {   // in units of R
+  return (kPhotonLdsBoxes * (int)sizeof(DPhotonBox<R>) > kPhotonTop * (int)sizeof(DPhotonNode<R>) ? kPhotonLdsBoxes * (int)sizeof(DPhotonBox<R>)
+                                                                                                      : kPhotonTop * (int)sizeof(DPhotonNode<R>)) / (int)sizeof(R);
+}
 
-// Fills `top` (all threads of the workgroup; the caller synchronises afterwards).
-template <class R> RTX_DEV void photon_stage_top(const DRenderParams& P, DPhotonNode<R>* top) {
-  const DPhotonNode<R>* nodes = (const DPhotonNode<R>*)P.ph_nodes;
-  for (int h = 1 + (int)threadIdx.x; h < kPhotonTop; h += (int)blockDim.x) {
-    const int level = 31 - __clz(h);
-    int s = 0, e = P.n_photons;
-    for (int i = level - 1; i >= 0 && s < e; --i) {
-      const int m = s + (e - s) / 2;
-      if ((h >> i) & 1) s = m + 1; else e = m;
+// d2, id: this wave's candidate list in LDS.  top / lbox: the workgroup's photon table seen as tree top or as boxes;
+// lds_groups, lds_runs: whether the group boxes (at lbox[g]) and the run boxes (at lbox[n_groups + r]) are in it.
+template <class R> struct PhotonCand {
+  R* d2; int* id;
+  const DPhotonNode<R>* top;
+  const DPhotonBox<R>* lbox;
+  bool lds_groups, lds_runs;
+};
+
+// Fills the photon table (all threads of the workgroup; the caller synchronises afterwards) and completes `pc`.
+template <class R> RTX_DEV void photon_stage_table(const DRenderParams& P, R* table, PhotonCand<R>& pc) {
+  pc.top = reinterpret_cast<const DPhotonNode<R>*>(table);
+  pc.lbox = reinterpret_cast<const DPhotonBox<R>*>(table);
+  pc.lds_groups = pc.lds_runs = false;
+  if (P.n_photons <= 0) return;
+  if (P.n_photons > P.ph_bucket) {
+    DPhotonNode<R>* top = reinterpret_cast<DPhotonNode<R>*>(table);
+    const DPhotonNode<R>* nodes = (const DPhotonNode<R>*)P.ph_nodes;
+    for (int h = 1 + (int)threadIdx.x; h < kPhotonTop; h += (int)blockDim.x) {
+      const int level = 31 - __clz(h);
+      int s = 0, e = P.n_photons;
+      for (int i = level - 1; i >= 0 && s < e; --i) {
+        const int m = s + (e - s) / 2;
+        if ((h >> i) & 1) s = m + 1; else e = m;
+      }
+      if (s < e) top[h] = nodes[s + (e - s) / 2];
     }
-    if (s < e) top[h] = nodes[s + (e - s) / 2];
+    return;
   }
+  const int n_runs = (P.n_photons + 63) / 64, n_groups = (n_runs + 63) / 64;
+  pc.lds_groups = n_groups <= kPhotonLdsBoxes;
+  pc.lds_runs = n_groups + n_runs <= kPhotonLdsBoxes;
+  DPhotonBox<R>* lbox = reinterpret_cast<DPhotonBox<R>*>(table);
+  const DPhotonBox<R>* boxes = (const DPhotonBox<R>*)P.ph_boxes;   // run boxes, then group boxes
+  if (pc.lds_groups)
+    for (int g = (int)threadIdx.x; g < n_groups; g += (int)blockDim.x) lbox[g] = boxes[n_runs + g];
+  if (pc.lds_runs)
+    for (int r = (int)threadIdx.x; r < n_runs; r += (int)blockDim.x) lbox[n_groups + r] = boxes[r];
 }
 
 RTX_DEV uint32_t dist_key(float v) { return __float_as_uint(v); }
@@ -124,13 +156,14 @@ template <class R> RTX_DEV R photon_select(PhotonCand<R> pc, int& n, const int k
 template <class R> RTX_DEV void photon_scan(const DRenderParams& P, const V3<R> pos, const int start, const int end, PhotonCand<R> pc, int& n, R& bound, const int lane) {
   const DPhotonNode<R>* nodes = (const DPhotonNode<R>*)P.ph_nodes;
   const DPhotonBox<R>* boxes = (const DPhotonBox<R>*)P.ph_boxes;     // box r: photons [64 r, 64 r + 64)
+  const int n_groups = ((P.n_photons + 63) / 64 + 63) / 64;
   const DPhotonBox<R>* groups = boxes + (P.n_photons + 63) / 64;      // box g: runs [64 g, 64 g + 64)
   const int k = P.gather_k;
   const int select_at = (kPhotonCand - 64 < k + 64) ? kPhotonCand - 64 : k + 64;   // list length that triggers a selection (> k)
   const int run0 = start >> 6, run1 = (end - 1) >> 6;
   for (int gb = run0 >> 6; gb <= run1 >> 6; gb += 64) {
     R group_d2 = bound;
-    if (gb + lane <= run1 >> 6) group_d2 = box_distance2(groups[gb + lane], pos);
+    if (gb + lane <= run1 >> 6) group_d2 = box_distance2(pc.lds_groups ? pc.lbox[gb + lane] : groups[gb + lane], pos);
     unsigned long long todo = __ballot(group_d2 < bound);
     while (todo != 0ull) {
       const int gl = (int)__ffsll((long long)todo) - 1;
@@ -138,7 +171,7 @@ template <class R> RTX_DEV void photon_scan(const DRenderParams& P, const V3<R> 
       if (!(lane_value(group_d2, gl) < bound)) continue;   // the bound may have tightened since the box was tested
       const int rb = (gb + gl) * 64;
       R run_d2 = bound;
-      if (rb + lane >= run0 && rb + lane <= run1) run_d2 = box_distance2(boxes[rb + lane], pos);
+      if (rb + lane >= run0 && rb + lane <= run1) run_d2 = box_distance2(pc.lds_runs ? pc.lbox[n_groups + rb + lane] : boxes[rb + lane], pos);
       unsigned long long runs = __ballot(run_d2 < bound);
       while (runs != 0ull) {   // kPhotonUnroll runs per trip: their loads are issued together
         int first[kPhotonUnroll];
