@@ -226,6 +226,7 @@ def test_bdpt_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
 @pytest.mark.parametrize("name,nee,photons,k,radius", [("cornell_box", 1, 4000, 40, 0.3), ("cornell_box", 0, 1500, 10, 0.1), ("kitchen_points", 1, 3000, 25, 0.25),
                                                         ("textured", 1, 3000, 100, 0.5), ("normal_mapped", 1, 3000, 30, 0.3), ("cornell_box_quad", 1, 2000, 20, 0.2),
                                                         ("cornell_box", 1, 60000, 50, 0.15),   # enough photons for a kd-tree several levels deep above the GPU's buckets
+                                                        ("cornell_box", 1, 90000, 40, 0.12),   # not walked, and more bounding boxes than the GPU keeps in LDS
                                                         ("soup_box", 1, 3000, 30, 0.3)])        # cornell_box + 600 triangles: the instances that walk a BVH with an LDS stack
 def test_pathphoton_film_equals_oracle(name, nee, photons, k, radius, pkg, oracle, tracer, load_scene, monkeypatch):
     """RenderMode::PathPhoton (engine/renderer.cpp:344-372 photon pass, :844-976 integrator): the GPU traces the caustic photons
