@@ -3,11 +3,12 @@
 //
 //   the REFERENCE's SceneLoader::load  ->  the REFERENCE's Scene / Camera objects
 //        -> ray-tracer_amd/host/reference_adapter.hpp -> C ABI -> MI355X kernels      (film A)
-//        -> the REFERENCE's own Renderer::render on the host cores (use_mnee = false)  (film B)
+//        -> the REFERENCE's own Renderer::render on the host cores (use_mnee = false unless asked for)  (film B)
 //
 //   ref_hip_driver <scene.json> <W> <H> <spp_gpu> <spp_cpu> <depth> <threads> <out_prefix> [cpu_seed [mode [photons gather_count gather_radius]]]
 // (mode: RenderMode value, 1 = PathTrace by default, 0 = Whitted, 2 = BDPT, 6 = PathPhoton; both renderers use it.
-//  The three photon arguments replace Renderer::Settings' caustic photon defaults.)
+//  The three photon arguments replace Renderer::Settings' caustic photon defaults.  A mode written with a trailing 'm',
+//  e.g. 1m, switches use_mnee on for both renderers.)
 // writes <out_prefix>_gpu.bin (float32) and <out_prefix>_cpu.bin (float64, unclamped) and
 // prints timings.  spp_cpu = 0 skips the CPU render.
 #include <omp.h>
@@ -15,6 +16,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <string>
 #include <vector>
@@ -37,7 +39,7 @@ int main(int argc, char** argv) {
   const int mode = argc > 10 ? atoi(argv[10]) : 1;
   st.mode = mode == 0 ? RenderMode::Whitted : mode == 2 ? RenderMode::BDPT : mode == 6 ? RenderMode::PathPhoton : RenderMode::PathTrace;
   if (argc > 13) { st.caustic_photon_count = (size_t)strtoull(argv[11], nullptr, 10); st.photon_gather_count = atoi(argv[12]); st.caustic_gather_radius = (float)atof(argv[13]); }
-  st.use_nee = data.use_nee; st.use_mis = data.use_mis; st.use_mnee = false;
+  st.use_nee = data.use_nee; st.use_mis = data.use_mis; st.use_mnee = argc > 10 && strchr(argv[10], 'm') != nullptr;
   st.background_color = data.background_color; st.background_top = data.background_top;
   st.background_bottom = data.background_bottom; st.use_background_gradient = data.use_background_gradient;
   Camera cam(data.camera_position, data.camera_target, data.camera_up, data.camera_fov, (double)W / H);
