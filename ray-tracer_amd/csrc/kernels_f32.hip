@@ -35,7 +35,11 @@ int launch_render_bdpt(const DScene<float>& sc, const DCamera<float>& cam, const
 int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
                         const FusedLaunch& L, hipStream_t stream) {
   dim3 g(L.grid), b(kBlock);
-  if (L.integ == INTEG_PATHPHOTON) {   // as Whitted: the general (TREE_UV) instances only
+  if (L.integ == INTEG_PATHPHOTON) {   // the flat instance or the general (TREE_UV) ones
+    if (L.mode == MODE_FLAT && L.lds_mats) {
+      hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATHPHOTON>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+      return 0;
+    }
     if (L.mode != MODE_TREE_UV) return -1;
     if (L.lds_mats) hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, true, INTEG_PATHPHOTON>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     else hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, false, INTEG_PATHPHOTON>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);

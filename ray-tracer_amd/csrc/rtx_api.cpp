@@ -324,7 +324,8 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     if (items >= 0x7fffffffull) return fail(RTX_ERR_INVALID_ARGUMENT, "film too large for one launch (%llu work items)", items);
     if (!c->partial.ensure((size_t)items * 3 * elem)) return fail(RTX_ERR_OUT_OF_MEMORY, "chunk-sum buffer (%llu bytes)", (unsigned long long)(items * 3 * elem));
     FusedLaunch L;
-    L.mode = (whitted || photon) ? MODE_TREE_UV : c->scene.fused_mode(f64);
+    L.mode = whitted ? MODE_TREE_UV : c->scene.fused_mode(f64);
+    if (photon && L.mode != MODE_FLAT) L.mode = MODE_TREE_UV;   // PathPhoton: the flat instance (single precision, small untextured scenes) or the general one
     if (bdpt && L.mode == MODE_TREE) L.mode = MODE_TREE_UV;
     L.integ = whitted ? INTEG_WHITTED : bdpt ? INTEG_BDPT : photon ? INTEG_PATHPHOTON : mnee ? INTEG_PATH_MNEE : INTEG_PATH;
     const size_t mat_bytes = (size_t)c->scene.dev_f.n_mats * (f64 ? sizeof(DMaterial<double>) : sizeof(DMaterial<float>));
