@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pt_host.hpp"
@@ -58,15 +59,24 @@ struct rtx_ctx {
 // photons per emissive sphere on the host, trace them on the GPU, build the kd-tree on the host as PhotonMap::build does
 // (ref: engine/photon_map.hpp:104-108, :222-245) and hand it to the render through P.
 namespace {
-struct HostPhoton { double p[3], dir[3], power[3]; int axis; };
-void photon_build_tree(std::vector<HostPhoton>& ph, size_t start, size_t end, int depth) {
+// The tree is built over (position, photon index) keys: std::nth_element's moves depend on the comparisons only, so the
+// arrangement is the one the reference gets on its photon records, at a third of the bytes moved.  The two sides of a split are
+// independent; the first levels build them on separate threads.
+struct PhotonKey { double p[3]; uint32_t idx; int32_t axis; };
+void photon_build_tree(PhotonKey* ph, size_t start, size_t end, int depth) {
   if (end - start <= 1) return;
   const int axis = depth % 3;
   const size_t mid = start + (end - start) / 2;
-  std::nth_element(ph.begin() + start, ph.begin() + mid, ph.begin() + end, [axis](const HostPhoton& a, const HostPhoton& b) { return a.p[axis] < b.p[axis]; });
+  std::nth_element(ph + start, ph + mid, ph + end, [axis](const PhotonKey& a, const PhotonKey& b) { return a.p[axis] < b.p[axis]; });
   ph[mid].axis = axis;
-  photon_build_tree(ph, start, mid, depth + 1);
-  photon_build_tree(ph, mid + 1, end, depth + 1);
+  if (depth < 4 && end - start > 8192) {
+    std::thread left(photon_build_tree, ph, start, mid, depth + 1);
+    photon_build_tree(ph, mid + 1, end, depth + 1);
+    left.join();
+  } else {
+    photon_build_tree(ph, start, mid, depth + 1);
+    photon_build_tree(ph, mid + 1, end, depth + 1);
+  }
 }
 template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderParams& P, const DScene<R>& sc, size_t lds_bytes, hipStream_t stream) {
   const double kPi = 3.14159265358979323846;
@@ -113,20 +123,24 @@ template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderPar
   std::vector<R> raw((size_t)n * 10);
   HIP_TRY(hipMemcpyAsync(raw.data(), c->ph_out.ptr, raw.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
-  std::vector<HostPhoton> ph;
+  std::vector<PhotonKey> ph;
+  ph.reserve(n);
   for (uint32_t i = 0; i < n; ++i) {   // in emission order, as the reference's push_back sequence
     if (raw[(size_t)9 * n + i] == R(0)) continue;
-    HostPhoton q;
-    for (int a = 0; a < 3; ++a) { q.p[a] = (double)raw[(size_t)a * n + i]; q.dir[a] = (double)raw[(size_t)(3 + a) * n + i]; q.power[a] = (double)raw[(size_t)(6 + a) * n + i]; }
-    q.axis = 0;
+    PhotonKey q;
+    for (int a = 0; a < 3; ++a) q.p[a] = (double)raw[(size_t)a * n + i];
+    q.idx = i; q.axis = 0;
     ph.push_back(q);
   }
   if (ph.empty()) return RTX_OK;
-  photon_build_tree(ph, 0, ph.size(), 0);
+  photon_build_tree(ph.data(), 0, ph.size(), 0);
   std::vector<DPhotonNode<R>> nodes(ph.size());
   std::vector<DPhotonData<R>> data(ph.size());
-  for (size_t i = 0; i < ph.size(); ++i)
-    for (int a = 0; a < 3; ++a) { nodes[i].p[a] = (R)ph[i].p[a]; nodes[i].axis = ph[i].axis; data[i].dir[a] = (R)ph[i].dir[a]; data[i].power[a] = (R)ph[i].power[a]; }
+  for (size_t i = 0; i < ph.size(); ++i) {
+    const size_t src = ph[i].idx;
+    nodes[i].axis = ph[i].axis;
+    for (int a = 0; a < 3; ++a) { nodes[i].p[a] = raw[(size_t)a * n + src]; data[i].dir[a] = raw[(size_t)(3 + a) * n + src]; data[i].power[a] = raw[(size_t)(6 + a) * n + src]; }
+  }
   // Neighbours in the tree's array are neighbours in space: the box of every run of 64 photons lets the search skip the run,
   // the box of every group of 64 runs (stored after the run boxes) the group.
   const size_t n_runs = (nodes.size() + 63) / 64, n_groups = (n_runs + 63) / 64;
