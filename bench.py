@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Cornell box path tracing with NEE + MIS on MI355X.
+"""Headline benchmark: path tracing with NEE + MIS on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c5]
 
-One "step" is one complete render of the workload (default: scenes/cornell_box.json at
-1920x1080, 1024 spp, max_depth 500, NEE + MIS, manifold NEE off — the configuration the
-headline metric is quoted on).  With N > 1 (launched by torch.distributed.run, one rank per
-GPU) the image's rows are interleaved over the ranks and the film is gathered to rank 0
-over RCCL inside the timed region; total work is fixed, so scaling is "strong".
+One "step" is one complete render of the configuration's workload:
+
+  c2 (default, the configuration the headline metric is quoted on)
+      scenes/cornell_box.json at 1920x1080, 1024 spp, max_depth 500, NEE + MIS, manifold NEE off
+  c3  scenes/cornell_box_quad.json (depth 50) and scenes/caustics_test.json (depth 16, as a path tracer), 800x800, 128 spp each
+  c5  the synthetic BVH stress scene: 10 M triangles, 1920x1080, 64 spp, max_depth 8
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the image's rows are interleaved over the ranks and the
+film is gathered to rank 0 over RCCL inside the timed region; total work is fixed, so scaling is "strong".
 
 Rank 0 prints ONE JSON line.  `value` = samples of all ranks / max-over-ranks time.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -19,12 +24,30 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E peak (spec)
-# Algorithmic bytes of a wavefront path tracer per unit of work: path state written + read
-# (96 B) + hit record (32 B) + two queue indices (16 B) per path segment; 88 B per shadow ray;
-# 24 B of film accumulation per sample.
+# Vector-ALU issue ceiling: 256 CUs x 4 SIMDs, one wave64 instruction per SIMD every VALU_CYCLES_PER_INST cycles at 2.4 GHz
+# (measured with scripts/valu_peak.hip: profiles/r02_valu_peak.jsonl).
+N_SIMDS, CLOCK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 4.0
+# What a queue-based path tracer would move per unit of work (path state written + read 96 B + hit record 32 B + two queue
+# indices 16 B per path segment; 88 B per shadow ray; 24 B of film accumulation per sample): reported as an equivalent
+# rate only; the fused kernel keeps that state in registers.
 BYTES_PER_SEGMENT, BYTES_PER_SHADOW_RAY, BYTES_PER_SAMPLE = 144, 88, 24
+
+CONFIGS = {
+    "c2": [("cornell_box", 1920, 1080, 1024, 500)],
+    "c3": [("cornell_box_quad", 800, 800, 128, 50), ("caustics_test", 800, 800, 128, 16)],
+    "c5": [("stress10m", 1920, 1080, 64, 8)],
+}
+
+
+def sha256_of(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
 
 
 def main():
@@ -32,13 +55,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "scenes", "cornell_box.json"))
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=1024)
-    ap.add_argument("--max-depth", type=int, default=500)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--spp", type=int, default=0, help="override the configuration's samples per pixel (the line then says so)")
     ap.add_argument("--pipeline", choices=["auto", "fused", "wavefront"], default="auto")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the double-precision and id-agreement legs (profiling runs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -61,52 +82,62 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    sd = pkg.scene_loader.load(args.scene)
-    W, H, spp = args.width, args.height, args.spp
     pipeline = {"auto": abi.PIPELINE_AUTO, "fused": abi.PIPELINE_FUSED, "wavefront": abi.PIPELINE_WAVEFRONT}[args.pipeline]
-    st = sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=args.max_depth, use_nee=1, use_mis=1, seed=1234,
-                     precision=abi.PRECISION_F32, pipeline=pipeline, shard_index=rank, shard_count=world)
-    pt = pkg.renderer.HipPathTracer(local_rank)
-    pt.set_settings(st)
-    pt.upload_scene(sd)                       # inputs are resident in HBM before the timed region
-    pt.set_camera(sd.camera(W, H))
-    rows = parallel.shard_rows(H, rank, world)
-    local = torch.empty((rows, W, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream().cuda_stream
+    jobs = []   # one per scene of the configuration: tracer, scene, film tensor, sizes
+    upload_s = 0.0
+    for (name, W, H, spp, depth) in CONFIGS[args.config]:
+        spp = args.spp or spp
+        sd = pkg.synthetic.stress_scene(10_000_000) if name == "stress10m" else pkg.scene_loader.load(os.path.join(SCENES, name + ".json"))
+        st = sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=depth, use_nee=1, use_mis=1, seed=1234, mode=abi.MODE_PATHTRACE,
+                         precision=abi.PRECISION_F32, pipeline=pipeline, shard_index=rank, shard_count=world)
+        pt = pkg.renderer.HipPathTracer(local_rank)
+        pt.set_settings(st)
+        t0 = time.perf_counter()
+        pt.upload_scene(sd)                       # inputs are resident in HBM before the timed region
+        upload_s += time.perf_counter() - t0
+        pt.set_camera(sd.camera(W, H))
+        rows = parallel.shard_rows(H, rank, world)
+        local = torch.empty((rows, W, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
+        jobs.append(dict(name=name, W=W, H=H, spp=spp, depth=depth, sd=sd, pt=pt, local=local, settings=st))
 
     stats = []
     gather_events = []   # rank 0, N > 1: the film gather of every timed step, bracketed by events on torch's stream
 
     def step():
-        s = pt.render_device(local.data_ptr(), stream)   # kernels on torch's current stream; returns when they are done
-        stats.append((s.samples, s.rays_closest, s.rays_shadow, s.segments, s.seconds_main_kernel, s.seconds_render))
-        if world == 1:
-            return parallel.gather_film(local, H, W, rank, world)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        full = parallel.gather_film(local, H, W, rank, world)
-        e1.record()
-        gather_events.append((e0, e1))
-        return full
+        films = []
+        for j in jobs:
+            s = j["pt"].render_device(j["local"].data_ptr(), stream)   # kernels on torch's current stream; returns when they are done
+            stats.append(s)
+            if world == 1:
+                films.append(parallel.gather_film(j["local"], j["H"], j["W"], rank, world))
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            films.append(parallel.gather_film(j["local"], j["H"], j["W"], rank, world))
+            e1.record()
+            gather_events.append((e0, e1))
+        return films
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    film = None
+    films = None
     for _ in range(args.warmup):
-        film = step()
+        films = step()
     stats.clear()
     gather_events.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        film = step()
+        films = step()
     fence()
     elapsed = time.perf_counter() - t0
     tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-    tot = torch.tensor([float(sum(s[0] for s in stats)), float(sum(s[1] + s[2] for s in stats))], dtype=torch.float64, device=f"cuda:{local_rank}")
+    tot = torch.tensor([float(sum(s.samples for s in stats)), float(sum(s.rays_closest + s.rays_shadow for s in stats))], dtype=torch.float64,
+                       device=f"cuda:{local_rank}")
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -114,42 +145,13 @@ def main():
     total_samples, total_rays = float(tot[0].item()), float(tot[1].item())
 
     if rank == 0:
-        assert film is not None and tuple(film.shape) == (H, W, 3)
-        assert total_samples == float(W) * H * spp * args.steps, "work was skipped inside the timed region"
-        mean_radiance = float(film.clamp(0, 1).mean().item())
-        # dominant kernel (rank 0's launches): algorithmic bytes / measured kernel time
-        n = len(stats)
-        seg = sum(s[3] for s in stats) / n
-        shd = sum(s[2] for s in stats) / n
-        smp = sum(s[0] for s in stats) / n
-        kern_s = sum(s[4] for s in stats) / n
-        alg_bytes = BYTES_PER_SEGMENT * seg + BYTES_PER_SHADOW_RAY * shd + BYTES_PER_SAMPLE * smp
-        achieved = alg_bytes / kern_s / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("workload") == [os.path.basename(args.scene), W, H, spp] and world == 1:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
-                pass
-        # What actually limits the kernel (from the committed PMC profile of this workload, not measured live):
-        # VALU issue slots in use = wave-instructions x 4 cycles / (SIMDs x active cycles), and the share of lanes
-        # active per VALU instruction.
-        valu = None
-        prof = os.path.join(ROOT, "profiles", "r01_fused_flat", "pmc_per_launch.json")
-        if traffic is not None and os.path.exists(prof):
-            try:
-                c = json.load(open(prof))
-                cycles = c["GRBM_GUI_ACTIVE"] / 8.0            # summed over the 8 XCDs
-                valu = {"issue_busy": c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles),
-                        "lanes_active": c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0),
-                        "source": "profiles/r01_fused_flat/pmc_per_launch.json"}
-            except (OSError, ValueError, KeyError, ZeroDivisionError):
-                pass
+        expect = sum(j["W"] * j["H"] * j["spp"] for j in jobs) * args.steps
+        assert films is not None and all(tuple(f.shape) == (j["H"], j["W"], 3) for f, j in zip(films, jobs))
+        assert total_samples == float(expect), "work was skipped inside the timed region"
+        workload = " + ".join(f"{j['name']} {j['W']}x{j['H']} {j['spp']}spp max_depth={j['depth']}" for j in jobs) + " NEE+MIS mnee=off"
+        last = jobs[0]["pt"].last_stats
         out = {
-            "metric": "Msamples/s (Cornell box, NEE+MIS path tracing; Mrays/s alongside)",
+            "metric": "Msamples/s (NEE+MIS path tracing; Mrays/s alongside)",
             "value": total_samples / elapsed / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -158,74 +160,183 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (scene generated from the reference's cornell_box.json description; no image assets)",
-            "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H} {spp}spp max_depth={args.max_depth} NEE+MIS mnee=off",
+            "data": "synthetic (scenes built from the reference's scene descriptions / generated in code; no image assets)",
+            "config": {"workload": workload, "name": args.config,
                        "parallelism": f"row-interleaved x{world}, film gather over RCCL" if world > 1 else "single GPU",
-                       "pipeline": {abi.PIPELINE_FUSED: "fused", abi.PIPELINE_WAVEFRONT: "wavefront"}.get(pt.last_stats.pipeline_used, "?"),
-                       "seed": 1234},
+                       "pipeline": {abi.PIPELINE_FUSED: "fused", abi.PIPELINE_WAVEFRONT: "wavefront"}.get(last.pipeline_used, "?"),
+                       "seed": 1234, "scene_upload_and_bvh_s": upload_s},
             "mrays_per_s": total_rays / elapsed / 1e6,
             "mrays_per_s_per_gpu": total_rays / elapsed / 1e6 / world,
             "msamples_per_s_per_gpu": total_samples / elapsed / 1e6 / world,
-            "segments_per_sample": seg / smp,
-            "film_mean_clamped": mean_radiance,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "valu": valu,
-                         "note": "algorithmic bytes are the per-segment / per-shadow-ray / per-sample figures of a queue-based pipeline; the fused "
-                                 "kernel keeps that state in registers (see traffic), so frac can exceed 1: the kernel is VALU-issue bound (see valu)",
-                         "kernel": "render_fused_kernel<float>" if pt.last_stats.pipeline_used == abi.PIPELINE_FUSED else "wavefront iteration kernels",
-                         "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
+            "film_mean_clamped": [float(f.clamp(0, 1).mean().item()) for f in films],
+            "roofline": roofline(args, abi, jobs, stats, world),
         }
         if world > 1 and gather_events:
             # rank 0's view: waiting for the slowest rank + the transfers + re-interleaving the rows
             g_ms = sum(a.elapsed_time(b) for a, b in gather_events) / len(gather_events)
-            into_root = (world - 1) * parallel.shard_rows(H, 0, world) * W * 3 * 4
-            out["film_gather"] = {"ms_per_step_incl_wait": g_ms, "bytes_into_rank0": into_root,
+            into_root = sum((world - 1) * parallel.shard_rows(j["H"], 0, world) * j["W"] * 3 * 4 for j in jobs) / len(jobs)
+            out["film_gather"] = {"ms_per_render_incl_wait": g_ms, "bytes_into_rank0": into_root,
                                   "GBps_lower_bound": into_root / (g_ms * 1e-3) / 1e9 if g_ms > 0 else None}
+        if world == 1 and not args.no_extras:
+            out["f64"] = f64_leg(pkg, jobs[0])
+            out["id_mismatch_f32"] = id_mismatch_leg(pkg, np, jobs[0])
         if world == 1 and args.cpu_baseline_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(pkg, sd, args)
+            out["cpu_baseline"] = cpu_baseline(pkg, jobs[0], args)
         print(json.dumps(out), flush=True)
-    pt.close()
+    for j in jobs:
+        j["pt"].close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(pkg, sd, args):
-    """CPU renderer timed on this host's cores on a bounded sample of the same workload:
-    the REAL reference (oracle/_ref/ref_harness = its Renderer::render compiled in place, with
-    use_mnee = false) when that binary is present, else the CPU oracle (a restatement of it)."""
+def roofline(args, abi, jobs, stats, world):
+    """The dominant kernel of rank 0's launches against the ceiling that bounds it.
+
+    Fused pipeline (c2, c3): the scene sits in scalar registers and the path in vector registers, HBM sees next to nothing:
+    the bound is vector-ALU issue.  achieved = VALU wave-instructions per launch / the kernel time measured live (HIP events
+    on the launch stream, rtx_stats.seconds_main_kernel).  The instruction count is a property of (kernel binary, workload):
+    every lane's work items are fixed by its index, so it is taken from the committed rocprofv3 --pmc profile of this very
+    workload - and only if that profile names the shared library that has just been timed (SHA-256), else it is null.
+    Queue pipeline (c5): the traversal kernel is bound by incoherent line fetches: achieved = (node records visited x record
+    bytes + primitives tested x primitive bytes, both counted live by the kernel) / its time measured live."""
+    first = [s for i, s in enumerate(stats) if i % len(jobs) == 0]   # scene 0 of every step
+    n = len(first)
+    seg = sum(s.segments for s in first) / n
+    shd = sum(s.rays_shadow for s in first) / n
+    smp = sum(s.samples for s in first) / n
+    kern_s = sum(s.seconds_main_kernel for s in first) / n
+    j0 = jobs[0]
+    workload = [j0["name"], j0["W"], j0["H"], j0["spp"], j0["depth"], world]
+    prof = None
+    try:
+        allp = json.load(open(os.path.join(ROOT, "profiles", "bench_profiles.json")))
+        cand = allp.get(args.config)
+        if cand and cand.get("workload") == workload and cand.get("lib_sha256") == sha256_of(abi.LIB_PATH):
+            prof = cand
+    except (OSError, ValueError):
+        pass
+    fused = first[0].pipeline_used == abi.PIPELINE_FUSED
+    r = {"kernel_ms": kern_s * 1e3, "profile": "profiles/bench_profiles.json" if prof else None,
+         "profile_note": None if prof else "no committed PMC profile names this library build and workload: counter-derived figures are null"}
+    if fused:
+        peak = N_SIMDS * CLOCK_HZ / VALU_CYCLES_PER_INST / 1e9
+        r.update({"bound": "valu", "unit": "Gwave-inst/s", "peak": peak, "kernel": "render_fused_kernel<float>",
+                  "achieved": None, "frac": None, "lanes_active": None, "traffic": None, "hbm_frac": None})
+        if prof:
+            ach = prof["SQ_INSTS_VALU"] / kern_s / 1e9
+            r.update({"achieved": ach, "frac": ach / peak, "lanes_active": prof.get("lanes_active"), "traffic": prof.get("hbm_bytes_per_launch"),
+                      "hbm_frac": (prof["hbm_bytes_per_launch"] / kern_s / 1e9 / HBM_PEAK_GBPS) if prof.get("hbm_bytes_per_launch") else None,
+                      "valu_insts_per_segment": prof["SQ_INSTS_VALU"] * 64.0 / seg, "kernel_symbol": prof.get("kernel"),
+                      "kernel_ms_rocprof": prof.get("kernel_ms_rocprof")})
+        r["wavefront_equivalent_GBps"] = (BYTES_PER_SEGMENT * seg + BYTES_PER_SHADOW_RAY * shd + BYTES_PER_SAMPLE * smp) / kern_s / 1e9
+    else:
+        ext_s = sum(s.seconds_extend for s in first) / n
+        nodes = sum(s.nodes_visited for s in first) / n
+        prims = sum(s.prims_tested for s in first) / n
+        rays = sum(s.rays_closest for s in first) / n
+        info = j0["pt"].bvh_info()
+        rec_b = info.wide_bytes / max(1, info.wide_nodes)
+        r.update({"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "kernel": "wf_extend (closest-hit traversal of the ray queue)",
+                  "kernel_ms": ext_s * 1e3, "frame_ms": kern_s * 1e3, "achieved": None, "frac": None, "traffic": None})
+        if ext_s > 0 and nodes > 0:
+            alg = nodes * rec_b + prims * info.leaf_prim_bytes
+            r.update({"achieved": alg / ext_s / 1e9, "frac": alg / ext_s / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch_set": alg,
+                      "records_per_ray": nodes / rays, "prims_per_ray": prims / rays, "record_bytes": rec_b, "prim_bytes": info.leaf_prim_bytes,
+                      "grays_per_s_closest_hit": rays / ext_s / 1e9})
+        if prof:
+            r.update({"traffic": prof.get("hbm_bytes_per_launch"), "lanes_active": prof.get("lanes_active"), "kernel_ms_rocprof": prof.get("kernel_ms_rocprof")})
+    return r
+
+
+def f64_leg(pkg, job):
+    """The same workload in double precision (the reference's arithmetic type), at fewer samples per pixel."""
+    abi = pkg.abi
+    pt, sd = job["pt"], job["sd"]
+    spp = max(1, min(job["spp"], 32))
+    pt.set_settings(sd.settings(width=job["W"], height=job["H"], samples_per_pixel=spp, max_depth=job["depth"], use_nee=1, use_mis=1, seed=1234,
+                                mode=abi.MODE_PATHTRACE, precision=abi.PRECISION_F64))
+    best = None
+    for _ in range(2):
+        s = pt.render_device(job["local"].data_ptr())
+        best = s if best is None or s.seconds_render < best.seconds_render else best
+    pt.set_settings(job["settings"])
+    return {"spp": spp, "ms_per_step": best.seconds_render * 1e3, "msamples_per_s": best.samples / best.seconds_render / 1e6,
+            "mrays_per_s": (best.rays_closest + best.rays_shadow) / best.seconds_render / 1e6,
+            "pipeline": {abi.PIPELINE_FUSED: "fused", abi.PIPELINE_WAVEFRONT: "wavefront"}.get(best.pipeline_used, "?")}
+
+
+def id_mismatch_leg(pkg, np, job):
+    """Share of rays for which the single-precision production walk names another primitive than the double-precision
+    reference-order kernel (which the tests pin to the real reference bit for bit)."""
+    pt = job["pt"]
+    fx = os.path.join(ROOT, "tests", "golden", "hits", job["name"] + ".npz")
+    if job["name"] == "stress10m":
+        rays, what = pkg.synthetic.stress_rays(1_000_000, seed=4242), "1 M seeded incoherent rays"
+    elif os.path.exists(fx):
+        rays, what = np.load(fx)["rays"], "the fixture's pixel-centre and random rays"
+    else:
+        return None
+    ref = pt.trace_closest(rays)
+    f32 = pt.trace_closest(rays, pkg.abi.PRECISION_F32)
+    agree = (f32["hit"] == ref["hit"]) & (f32["prim_type"] == ref["prim_type"]) & (f32["prim_index"] == ref["prim_index"])
+    return {"rate": 1.0 - float(agree.mean()), "rays": int(len(rays)), "ray_set": what}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(pkg, job, args):
+    """CPU renderer timed on this host's cores on a bounded sample of the same workload: the REAL reference
+    (oracle/_ref/ref_harness = its Renderer::render compiled in place, use_mnee = false) when that binary is present and the
+    scene is one of its files, else the CPU oracle (a restatement of it).  Threads = the CPU share of the job: OMP_NUM_THREADS
+    where the launcher sets it (a one-GPU box hands 16 of the host's cores to a job and asks for pools of that size), else the
+    CPUs this process may run on."""
     import re
     import subprocess
     import tempfile
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or allowed
+    host = {"host_nproc": os.cpu_count(), "cpus_allowed": allowed, "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS"), "cpu_model": cpu_model()}
+    name, depth = job["name"], job["depth"]
+    scene_file = os.path.join(SCENES, name + ".json")
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-    if os.path.exists(ref):
-        W, H = 320, 180
-
+    W, H = 320, 180
+    if os.path.exists(ref) and os.path.exists(scene_file):
         def run(spp):
             with tempfile.TemporaryDirectory() as td:
-                o = subprocess.run([ref, "render", args.scene, str(W), str(H), str(spp), str(args.max_depth), "1", "1", "1", "0", str(threads),
+                o = subprocess.run([ref, "render", scene_file, str(W), str(H), str(spp), str(depth), "1", "1", "1", "0", str(threads),
                                     os.path.join(td, "f.bin")], cwd=os.path.join(ROOT, "tests", "golden"), capture_output=True, text=True, check=True).stdout
             return float(re.search(r"@@TIME@@ ([0-9.]+) s", o).group(1))
         try:
             t = run(4)
             spp = int(max(8, min(4096, args.cpu_baseline_seconds / max(t, 1e-3) * 4)))
             secs = run(spp)
-            return {"value": W * H * spp / secs / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "reference",
-                    "sample": f"reference Renderer::render (use_mnee=false) on {os.path.basename(args.scene)} {W}x{H} {spp}spp max_depth={args.max_depth} NEE+MIS, {secs:.1f} s"}
+            return {"value": W * H * spp / secs / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "reference", **host,
+                    "sample": f"reference Renderer::render (use_mnee=false) on {name}.json {W}x{H} {spp}spp max_depth={depth} NEE+MIS, {secs:.1f} s"}
         except (subprocess.CalledProcessError, OSError, AttributeError) as e:
             print(f"reference baseline failed ({e}); falling back to the port", file=sys.stderr)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
+    sd = job["sd"]
     osc = O.OracleScene(sd)
-    W, H = 320, 180
     cam = sd.camera(W, H)
     probe_spp = 4
-    _, ps = osc.render(cam, sd.settings(width=W, height=H, samples_per_pixel=probe_spp, max_depth=args.max_depth, seed=1), O.RNG_COUNTER, threads)
+    _, ps = osc.render(cam, sd.settings(width=W, height=H, samples_per_pixel=probe_spp, max_depth=depth, seed=1), O.RNG_COUNTER, threads)
     rate = W * H * probe_spp / max(ps.seconds_render, 1e-6)
     spp = int(max(8, min(2048, args.cpu_baseline_seconds * rate / (W * H))))
-    _, s = osc.render(cam, sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=args.max_depth, seed=2), O.RNG_COUNTER, threads)
-    return {"value": s.samples / s.seconds_render / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"{os.path.basename(args.scene)} {W}x{H} {spp}spp max_depth={args.max_depth} NEE+MIS (same scene and estimator, reduced resolution), {s.seconds_render:.1f} s",
+    _, s = osc.render(cam, sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=depth, seed=2), O.RNG_COUNTER, threads)
+    return {"value": s.samples / s.seconds_render / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", **host,
+            "sample": f"{name} {W}x{H} {spp}spp max_depth={depth} NEE+MIS (same scene and estimator, reduced resolution), {s.seconds_render:.1f} s",
             "mrays_per_s_reference_equivalent": (s.rays_closest + s.rays_shadow) / s.seconds_render / 1e6}
 
 

@@ -145,13 +145,18 @@ typedef struct rtx_stats {
   uint64_t rays_closest;     /* closest-hit queries executed */
   uint64_t rays_shadow;      /* shadow (any-hit) queries executed */
   uint64_t segments;         /* path vertices shaded */
-  double seconds_render;     /* device time of all render kernels of the call (HIP events) */
+  double seconds_render;     /* device time of the render kernels of the call (HIP events); PathPhoton: without the photon pass */
   double seconds_main_kernel;/* device time of the dominant kernel alone (fused: the path-tracing kernel) */
   double seconds_total;      /* wall time of the call */
   uint32_t kernel_launches;
   uint32_t pipeline_used;    /* RTX_PIPELINE_FUSED or _WAVEFRONT */
   uint32_t precision_used;   /* RTX_PRECISION_*: use_mnee promotes a single-precision request to double */
   uint32_t reserved_;
+  double seconds_photon_pass;/* PathPhoton: wall time of the photon pass (trace kernel, kd-tree build on the host, uploads); else 0 */
+  /* queue-based pipeline only (0 otherwise): the closest-hit traversal kernel of the ray queue */
+  double seconds_extend;     /* device time of its launches, summed (HIP events around each) */
+  uint64_t nodes_visited;    /* node records it fetched and tested */
+  uint64_t prims_tested;     /* leaf primitives it tested */
 } rtx_stats;
 
 /* One closest-hit result: the members of hit_record (core/hit.h:20-29) that identify the
@@ -222,7 +227,13 @@ int rtx_trace_closest_fast(rtx_ctx* ctx, const double* rays8, size_t n, int prec
 int rtx_shard_rows(int height, int shard_index, int shard_count);
 
 /* BVH statistics of the uploaded scene (0 when there is no bounded primitive). */
-typedef struct rtx_bvh_info { uint64_t ref_nodes, ref_prims, wide_nodes, wide_bytes; double build_seconds; } rtx_bvh_info;
+typedef struct rtx_bvh_info {
+  uint64_t ref_nodes, ref_prims;   /* the reference-order binary tree (validation entry point, tie ranks) */
+  uint64_t wide_nodes, wide_bytes; /* node records of the tree the single-precision integrator walks, and their total size */
+  double build_seconds;            /* host time of the reference-order build */
+  uint64_t leaf_prim_bytes;        /* size of one leaf primitive record of that tree */
+  uint64_t reserved_;
+} rtx_bvh_info;
 int rtx_get_bvh_info(rtx_ctx* ctx, rtx_bvh_info* out);
 
 const char* rtx_last_error(void);

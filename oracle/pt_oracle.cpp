@@ -15,6 +15,7 @@
 #include <cstring>
 #include <queue>
 #include <random>
+#include <map>
 #include <vector>
 
 namespace {
@@ -123,14 +124,29 @@ int longest_axis(const Box6& b) {  // bvh.hpp:100-107
   return 2;
 }
 
-int build_range(orc_scene& s, int start, int end) {
-  int me = (int)s.nodes.size();
-  s.nodes.emplace_back();
+// Nodes are numbered in preorder as the reference's emplace_back sequence numbers them (bvh.hpp:167-218): a node, its whole
+// left subtree, its right subtree.  The node count under a range depends on its length only, so every subtree's slot is
+// known before it is built and disjoint ranges can be built by different threads without changing a single node.
+struct NodeCount {
+  std::map<int, int> memo;
+  int operator()(int count) {
+    if (count <= 2) return 1;
+    auto it = memo.find(count);
+    if (it != memo.end()) return it->second;
+    const int l = count / 2;
+    const int v = 1 + (*this)(l) + (*this)(count - l);
+    memo[count] = v;
+    return v;
+  }
+  int lookup(int count) const { return count <= 2 ? 1 : memo.at(count); }
+};
+
+void build_range(orc_scene& s, const NodeCount& nc, int me, int start, int end) {
   Box6 bounds;
   for (int i = start; i < end; ++i) grow(bounds, s.prims[i].box);
   s.nodes[me].box = bounds;
   int count = end - start;
-  if (count <= 2) { s.nodes[me].first = start; s.nodes[me].count = count; return me; }
+  if (count <= 2) { s.nodes[me].first = start; s.nodes[me].count = count; return; }
   Box6 cb;
   for (int i = start; i < end; ++i) grow(cb, centroid(s.prims[i].box));
   int axis = longest_axis(cb);
@@ -144,11 +160,18 @@ int build_range(orc_scene& s, int start, int end) {
                      if (axis == 1) return ca.y < cb2.y;
                      return ca.z < cb2.z;
                    });
-  int l = build_range(s, start, mid);
-  int r = build_range(s, mid, end);
+  const int l = me + 1, r = me + 1 + nc.lookup(mid - start);
   s.nodes[me].left = l;
   s.nodes[me].right = r;
-  return me;
+  if (count > 65536) {
+#pragma omp task shared(s, nc) firstprivate(l, start, mid)
+    build_range(s, nc, l, start, mid);
+    build_range(s, nc, r, mid, end);
+#pragma omp taskwait
+  } else {
+    build_range(s, nc, l, start, mid);
+    build_range(s, nc, r, mid, end);
+  }
 }
 
 void build_bvh(orc_scene& s) {
@@ -171,8 +194,11 @@ void build_bvh(orc_scene& s) {
     s.prims.push_back(p);
   }
   if (s.prims.empty()) return;
-  s.nodes.reserve(s.prims.size() * 2);
-  build_range(s, 0, (int)s.prims.size());
+  NodeCount nc;
+  s.nodes.resize((size_t)nc((int)s.prims.size()));
+#pragma omp parallel
+#pragma omp single
+  build_range(s, nc, 0, 0, (int)s.prims.size());
 }
 
 // ----------------------------------------------------------------------------------------

@@ -89,7 +89,8 @@ class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("segments", C.c_uint64), ("seconds_render", C.c_double), ("seconds_main_kernel", C.c_double), ("seconds_total", C.c_double),
                 ("kernel_launches", C.c_uint32), ("pipeline_used", C.c_uint32),
-                ("precision_used", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("precision_used", C.c_uint32), ("reserved_", C.c_uint32), ("seconds_photon_pass", C.c_double),
+                ("seconds_extend", C.c_double), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64)]
 
 
 class Hit(C.Structure):
@@ -100,7 +101,7 @@ class Hit(C.Structure):
 
 class BvhInfo(C.Structure):
     _fields_ = [("ref_nodes", C.c_uint64), ("ref_prims", C.c_uint64), ("wide_nodes", C.c_uint64),
-                ("wide_bytes", C.c_uint64), ("build_seconds", C.c_double)]
+                ("wide_bytes", C.c_uint64), ("build_seconds", C.c_double), ("leaf_prim_bytes", C.c_uint64), ("reserved_", C.c_uint64)]
 
 
 assert C.sizeof(Hit) == 96
@@ -133,6 +134,37 @@ EXPORTS = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """Keep ONE HIP runtime in the process when torch is installed.
+
+    torch's ROCm wheels bundle their own runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) and link
+    against it by FILE name, which the dynamic loader does not match with a runtime already loaded under its
+    SONAME from /opt/rocm/lib.  With this library loaded before `import torch`, the process therefore ended up
+    with two HIP + HSA runtimes, and the second one cannot initialise the device that the first one holds: torch
+    then reports "No HIP GPUs are available".  Loading torch's copy first makes librtx_hip.so (which asks for the
+    SONAME) bind to it, whichever of the two modules is imported first.  torch itself is not imported here."""
+    if os.environ.get("RTX_KEEP_SYSTEM_HIP_RUNTIME"):
+        return
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return   # a runtime is already in the process: the loader will reuse it by SONAME
+    except OSError:
+        pass
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for d in spec.submodule_search_locations:
+        cand = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            return
+
+
 def load_library(path: str | None = None):
     """dlopen librtx_hip.so and attach signatures.  Raises if it has not been built."""
     global _lib
@@ -142,6 +174,7 @@ def load_library(path: str | None = None):
     if not os.path.exists(p):
         raise RuntimeError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    _share_torch_hip_runtime()
     lib = C.CDLL(p)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree

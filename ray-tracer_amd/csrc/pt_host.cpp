@@ -31,7 +31,27 @@ void DeviceBuffer::release() {
   if (ptr) (void)hipFree(ptr);
   ptr = nullptr; cap = 0;
 }
-void WavefrontPool::release() { state.release(); queues.release(); control.release(); spill.release(); }
+void WavefrontPool::release() {
+  state.release(); queues.release(); control.release(); spill.release();
+  for (hipEvent_t e : events) (void)hipEventDestroy(e);
+  events.clear(); events_used = 0;
+}
+bool WavefrontPool::mark(hipStream_t stream) {
+  if (events_used == events.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return false;
+    events.push_back(e);
+  }
+  return hipEventRecord(events[events_used++], stream) == hipSuccess;
+}
+double WavefrontPool::timed_seconds() const {
+  double s = 0.0;
+  for (size_t i = 0; i + 1 < events_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, events[i], events[i + 1]) == hipSuccess) s += ms * 1e-3;
+  }
+  return s;
+}
 
 // ------------------------------------------------------------------------------------------
 // Reference-order BVH.  Median split on the longest centroid axis with std::nth_element,

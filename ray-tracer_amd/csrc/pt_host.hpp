@@ -95,6 +95,11 @@ void launch_selftest(float* out, int n, hipStream_t stream);
 // Wavefront pipeline (wavefront.hip): queue storage + the per-iteration launch loop.
 struct WavefrontPool {
   DeviceBuffer state, queues, control, spill;
+  // HIP events around every launch of the closest-hit traversal kernel of the last render (pairs: before, after)
+  std::vector<hipEvent_t> events;
+  size_t events_used = 0;
+  bool mark(hipStream_t stream);     // record the next event on `stream`
+  double timed_seconds() const;      // sum over the pairs; call after the stream has been synchronised
   void release();
 };
 int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* d_film,

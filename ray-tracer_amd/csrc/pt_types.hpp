@@ -115,13 +115,14 @@ struct DRenderParams {
 // Default of DRenderParams::ph_bucket: 64 groups of 64 runs of 64 photons.  Measured on the 1080p Cornell box with 50 000 photons
 // (16 spp): walking down to 64 photons 896 ms, 1024: 470, 16384: 235, no walk: 156.
 constexpr int kPhotonBucket = 64 * 64 * 64;
+constexpr unsigned long long kPhotonMaxCount = 1ull << 26;   // caustic photons per render (5 GB of double-precision staging on the host)
 constexpr int kPhotonMaxGather = 128;   // largest photon_gather_count the density estimate supports
 struct DPhotonLight { int32_t sphere; uint32_t first, count; int32_t pad; double power[3]; };   // photons [first, first + count) leave this emissive sphere
 template <class R> struct DPhotonNode { R p[3]; int32_t axis; };       // kd-tree in the reference's implicit layout: the median of a range sits at its middle
 template <class R> struct DPhotonData { R dir[3]; R power[3]; };
 template <class R> struct DPhotonBox { R lo[3]; R hi[3]; };
 
-struct DCounters { unsigned long long samples, closest, shadow, segments; };
+struct DCounters { unsigned long long samples, closest, shadow, segments, nodes_visited, prims_tested; };
 
 // One closest-hit answer in the layout of rtx_hit (include/rtx_hip.h).
 struct DHitOut {

@@ -10,6 +10,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -28,6 +30,14 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   g_error = buf;
   return code;
+}
+
+// No exception may cross the C boundary: host allocations (staging vectors, threads) can throw.
+template <class F> int guarded(F&& f) {
+  try { return f(); }
+  catch (const std::bad_alloc&) { return fail(RTX_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+  catch (const std::exception& e) { return fail(RTX_ERR_HIP, "internal error: %s", e.what()); }
+  catch (...) { return fail(RTX_ERR_HIP, "internal error"); }
 }
 
 #define HIP_TRY(expr)                                                                              \
@@ -112,7 +122,8 @@ template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderPar
     total += n;
   }
   if (total == 0) return RTX_OK;
-  if (total >= 0x7fffffffull) return fail(RTX_ERR_INVALID_ARGUMENT, "caustic_photon_count %llu is too large", (unsigned long long)s->caustic_photon_count);
+  // the host stages every photon record once (10 values each) to build the kd-tree: bounded to what a host can hold
+  if (total > kPhotonMaxCount) return fail(RTX_ERR_INVALID_ARGUMENT, "caustic_photon_count %llu is too large (at most %llu)", (unsigned long long)s->caustic_photon_count, (unsigned long long)kPhotonMaxCount);
   const uint32_t n = (uint32_t)total;
   if (!c->ph_lights.upload(plan.data(), plan.size() * sizeof(DPhotonLight)) || !c->ph_targets.upload(targets.data(), targets.size() * sizeof(int32_t)) ||
       !c->ph_out.ensure((size_t)n * 10 * sizeof(R)))
@@ -193,7 +204,7 @@ int rtx_selftest(int device_id) {
   return RTX_OK;
 }
 
-int rtx_create(rtx_ctx** out_ctx, int device_id) {
+static int create_impl(rtx_ctx** out_ctx, int device_id) {
   if (!out_ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
   *out_ctx = nullptr;
   int n_dev = 0;
@@ -211,6 +222,7 @@ int rtx_create(rtx_ctx** out_ctx, int device_id) {
   *out_ctx = c;
   return RTX_OK;
 }
+int rtx_create(rtx_ctx** out_ctx, int device_id) { return guarded([&] { return create_impl(out_ctx, device_id); }); }
 
 int rtx_destroy(rtx_ctx* c) {
   if (!c) return RTX_OK;
@@ -228,7 +240,7 @@ int rtx_destroy(rtx_ctx* c) {
   return RTX_OK;
 }
 
-int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d) {
+static int upload_impl(rtx_ctx* c, const rtx_scene_desc* d) {
   if (!c || !d) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
   HIP_TRY(hipSetDevice(c->device));
   std::string err;
@@ -236,6 +248,11 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d) {
   if (rc != RTX_OK) { c->has_scene = false; return fail(rc, "upload_scene: %s", err.c_str()); }
   c->has_scene = true;
   return RTX_OK;
+}
+int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d) {
+  const int rc = guarded([&] { return upload_impl(c, d); });
+  if (rc != RTX_OK && c) c->has_scene = false;
+  return rc;
 }
 
 int rtx_set_camera(rtx_ctx* c, const rtx_camera* cam) {
@@ -254,8 +271,12 @@ int rtx_get_bvh_info(rtx_ctx* c, rtx_bvh_info* out) {
   if (!c || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
   if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "no scene uploaded");
   out->ref_nodes = c->scene.n_nodes; out->ref_prims = c->scene.n_prims;
-  out->wide_nodes = c->scene.n_nodes; out->wide_bytes = (uint64_t)c->scene.n_nodes * sizeof(DNode2<float>);
+  // the records the single-precision integrator walks (none for scenes small enough to be tested linearly)
+  out->wide_nodes = (uint64_t)c->scene.dev_f.n_wide;
+  out->wide_bytes = (uint64_t)c->scene.dev_f.n_wide * (c->scene.dev_f.wideq ? sizeof(DNodeWideQ) : sizeof(DNodeWide));
   out->build_seconds = c->scene.build_seconds;
+  out->leaf_prim_bytes = c->scene.dev_f.n_wide > 0 ? sizeof(DLeafPrim) : 0;
+  out->reserved_ = 0;
   return RTX_OK;
 }
 
@@ -331,7 +352,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DCounters), stream));
 
   const bool needs_stack = c->scene.n_prims > kLinearMaxPrims;
-  HIP_TRY(hipEventRecord(c->ev0, stream));
+  if (!photon) HIP_TRY(hipEventRecord(c->ev0, stream));   // PathPhoton records it behind its photon pass
   if (pipeline == RTX_PIPELINE_FUSED) {
     const size_t elem = f64 ? sizeof(double) : sizeof(float);
     const unsigned long long items = npix * (unsigned long long)P.n_chunks;
@@ -353,9 +374,14 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     L.grid = (int)std::min<unsigned long long>((items + kBlock - 1) / kBlock, (unsigned long long)c->n_cus * blocks_per_cu);
     int lrc;
     if (photon) {   // the photon pass comes first (ref: engine/renderer.cpp:344-372); its rays are counted as closest-hit queries
-      const size_t walk_lds = stack ? (size_t)kStackDepth * kBlock * sizeof(int) : 0;
+      // the photon kernel is the tree-walking instance whatever the render kernel is (a flat scene of 13 to 16 spheres walks
+      // its tree there), so its traversal stacks are sized from the scene alone
+      const size_t walk_lds = needs_stack ? (size_t)kStackDepth * kBlock * sizeof(int) : 0;
+      const auto ph0 = std::chrono::steady_clock::now();
       const int prc = f64 ? photon_pass(c, s, P, c->scene.dev_d, walk_lds, stream) : photon_pass(c, s, P, c->scene.dev_f, walk_lds, stream);
       if (prc != RTX_OK) return prc;
+      st.seconds_photon_pass = std::chrono::duration<double>(std::chrono::steady_clock::now() - ph0).count();
+      HIP_TRY(hipEventRecord(c->ev0, stream));
     }
     if (bdpt) {
       // every lane keeps the connectible vertices of its light subpath (at most max_depth + 1) in global memory;
@@ -380,7 +406,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
       launch_film_reduce((const float*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
     }
     if (lrc != 0) return fail(RTX_ERR_UNSUPPORTED, "no kernel instance for mode %d", L.mode);
-    st.kernel_launches = 2;
+    st.kernel_launches = photon ? 3 : 2;
   } else {
     std::string err;
     int rc = wavefront_render(c->wf, c->scene.dev_f, c->cam_f, P, d_film, (DCounters*)c->counters.ptr, c->n_cus, c->scene.fused_mode(false), needs_stack ? kWalkLdsLevels : 0, stream, st.kernel_launches, err);
@@ -396,6 +422,8 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   st.samples = hc.samples; st.rays_closest = hc.closest; st.rays_shadow = hc.shadow; st.segments = hc.segments;
+  st.nodes_visited = hc.nodes_visited; st.prims_tested = hc.prims_tested;
+  if (pipeline == RTX_PIPELINE_WAVEFRONT) st.seconds_extend = c->wf.timed_seconds();
   st.seconds_render = ms * 1e-3;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->evm));
   st.seconds_main_kernel = ms * 1e-3;
@@ -408,12 +436,12 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
 
 int rtx_render(rtx_ctx* c, const rtx_settings* s, float* out_rgb, rtx_stats* stats) {
   if (!out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "out_rgb is NULL");
-  return render_impl(c, s, out_rgb, nullptr, nullptr, stats);
+  return guarded([&] { return render_impl(c, s, out_rgb, nullptr, nullptr, stats); });
 }
 
 int rtx_render_device(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* hip_stream, rtx_stats* stats) {
   if (!d_out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "d_out_rgb is NULL");
-  return render_impl(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, stats);
+  return guarded([&] { return render_impl(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, stats); });
 }
 
 static int postprocess_impl(rtx_ctx* c, const float* h_film, const void* d_film, int width, int height, int mapper, double exposure, uint8_t* h_out,
@@ -443,12 +471,12 @@ static int postprocess_impl(rtx_ctx* c, const float* h_film, const void* d_film,
 
 int rtx_postprocess(rtx_ctx* c, const float* film_rgb, int width, int height, int tone_mapper, double exposure, uint8_t* out_rgb8) {
   if (!film_rgb || !out_rgb8) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL buffer");
-  return postprocess_impl(c, film_rgb, nullptr, width, height, tone_mapper, exposure, out_rgb8, nullptr, nullptr);
+  return guarded([&] { return postprocess_impl(c, film_rgb, nullptr, width, height, tone_mapper, exposure, out_rgb8, nullptr, nullptr); });
 }
 
 int rtx_postprocess_device(rtx_ctx* c, const void* d_film_rgb, int width, int height, int tone_mapper, double exposure, void* d_out_rgb8, void* hip_stream) {
   if (!d_film_rgb || !d_out_rgb8) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL buffer");
-  return postprocess_impl(c, nullptr, d_film_rgb, width, height, tone_mapper, exposure, nullptr, d_out_rgb8, (hipStream_t)hip_stream);
+  return guarded([&] { return postprocess_impl(c, nullptr, d_film_rgb, width, height, tone_mapper, exposure, nullptr, d_out_rgb8, (hipStream_t)hip_stream); });
 }
 
 static int trace_impl(rtx_ctx* c, const double* rays8, size_t n, rtx_hit* out, int mode /*0 ref, 1 fast f32, 2 fast f64*/) {
@@ -469,11 +497,11 @@ static int trace_impl(rtx_ctx* c, const double* rays8, size_t n, rtx_hit* out, i
   return RTX_OK;
 }
 
-int rtx_trace_closest(rtx_ctx* c, const double* rays8, size_t n, rtx_hit* out) { return trace_impl(c, rays8, n, out, 0); }
+int rtx_trace_closest(rtx_ctx* c, const double* rays8, size_t n, rtx_hit* out) { return guarded([&] { return trace_impl(c, rays8, n, out, 0); }); }
 
 int rtx_trace_closest_fast(rtx_ctx* c, const double* rays8, size_t n, int precision, rtx_hit* out) {
   if (precision != RTX_PRECISION_F32 && precision != RTX_PRECISION_F64) return fail(RTX_ERR_INVALID_ARGUMENT, "precision %d", precision);
-  return trace_impl(c, rays8, n, out, precision == RTX_PRECISION_F32 ? 1 : 2);
+  return guarded([&] { return trace_impl(c, rays8, n, out, precision == RTX_PRECISION_F32 ? 1 : 2); });
 }
 
 }  // extern "C"

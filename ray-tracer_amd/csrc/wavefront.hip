@@ -205,8 +205,9 @@ __device__ unsigned long long g_walk_stats[8];   // diagnostic build only
 #endif
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int q, int stack_levels, int* spill) {
+__global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int q, int stack_levels, int* spill, DCounters* counters) {
   const uint32_t n = ctl->n_q[q];
+  uint32_t n_nodes = 0, n_prims = 0;   // node records and leaf primitives this lane tested
   bool more = true;   // wave-uniform: the queue may still have entries
   LaneStack st = lane_stack(0, stack_levels);
   st.spill = spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x; st.spill_stride = (int)(gridDim.x * blockDim.x);
@@ -257,17 +258,26 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A
 #ifdef RTX_WALK_STATS
       { const unsigned long long mi = __ballot(inner); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_walk_stats[0], 1ull); if (mi) { atomicAdd(&g_walk_stats[1], 1ull); atomicAdd(&g_walk_stats[2], (unsigned long long)__popcll(mi)); } } }
 #endif
-      if (inner) pair_walk_inner(sc, ray, 0.001f, c, w, st);
+      if (inner) { pair_walk_inner(sc, ray, 0.001f, c, w, st); ++n_nodes; }
       // leaves wait until a batch of lanes has one, or until no lane has an inner node left
       const bool leaf = state == 1 && pair_walk_at_leaf(w);
       if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && pair_walk_at_inner(w)) == 0ull) {
 #ifdef RTX_WALK_STATS
         { const unsigned long long ml = __ballot(leaf); if ((threadIdx.x & 63) == 0 && ml) { atomicAdd(&g_walk_stats[3], 1ull); atomicAdd(&g_walk_stats[4], (unsigned long long)__popcll(ml)); } }
 #endif
-        if (leaf) pair_walk_leaf<false>(sc, ray, 0.001f, c, w, st);
+        if (leaf) { pair_walk_leaf<false>(sc, ray, 0.001f, c, w, st); ++n_prims; }
       }
       if (state == 1 && w.node == kWalkDone) state = 2;
     }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_nodes += (uint32_t)__shfl_xor((int)n_nodes, off, 64);
+    n_prims += (uint32_t)__shfl_xor((int)n_prims, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && (n_nodes | n_prims)) {
+    atomicAdd(&counters->nodes_visited, (unsigned long long)n_nodes);
+    atomicAdd(&counters->prims_tested, (unsigned long long)n_prims);
   }
 }
 
@@ -389,13 +399,15 @@ __global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays 
 template <int MODE> void launch_iteration_kernels(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, const WfArrays& A, WfControl* ctl,
                                                   float* partial, DCounters* counters, bool lds_mats, size_t mat_lds, int stack_levels, unsigned grid,
                                                   unsigned resident_blocks, int step /*0 first generate, 1 shade, 2 connect, 3 generate*/, int qa, int qb,
-                                                  hipStream_t stream, uint32_t& launches, int* spill) {
+                                                  hipStream_t stream, uint32_t& launches, int* spill, WavefrontPool& pool) {
   const dim3 g((grid + (kStreamBlock / kBlock) - 1) / (kStreamBlock / kBlock)), bs(kStreamBlock), b(kBlock);   // `grid` counts kBlock-sized groups
   const dim3 gw(grid < resident_blocks ? grid : resident_blocks);   // persistent traversal kernels
   const size_t walk_lds = MODE == MODE_FLAT ? 0 : (size_t)stack_levels * kBlock * sizeof(int);
   if (step == 0 || step == 3) {
     hipLaunchKernelGGL(wf_generate, g, bs, 0, stream, cam, P, A, ctl, step == 0 ? 1 : 0, qa, qb, partial, counters);
-    hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, qb, stack_levels, spill);
+    pool.mark(stream);
+    hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, qb, stack_levels, spill, counters);
+    pool.mark(stream);
     ++launches;
   } else if (step == 1) {
     if (MODE == MODE_TREE_UV && sc.n_nmaps > 0) {   // the instances that apply normal maps
@@ -463,12 +475,13 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   int* spill = (int*)pool.spill.ptr;
 
   auto run = [&](int step, int qa, int qb, unsigned grid) {
-    if (mode == MODE_FLAT) launch_iteration_kernels<MODE_FLAT>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill);
-    else if (mode == MODE_TREE) launch_iteration_kernels<MODE_TREE>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill);
-    else launch_iteration_kernels<MODE_TREE_UV>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill);
+    if (mode == MODE_FLAT) launch_iteration_kernels<MODE_FLAT>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill, pool);
+    else if (mode == MODE_TREE) launch_iteration_kernels<MODE_TREE>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill, pool);
+    else launch_iteration_kernels<MODE_TREE_UV>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill, pool);
     ++launches;
   };
   if (hipMemsetAsync(ctl, 0, sizeof(WfControl), stream) != hipSuccess) { err = "memset"; return RTX_ERR_HIP; }
+  pool.events_used = 0;
   unsigned live_bound = n_slots;   // upper bound of the ray queue length (it only shrinks)
   unsigned grid = (live_bound + kBlock - 1) / kBlock;
   run(0, 0, 0, grid);

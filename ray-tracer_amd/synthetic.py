@@ -73,3 +73,49 @@ def stress_scene(n_triangles: int = 10_000_000, seed: int = 42) -> SceneData:
     sd.width, sd.height, sd.samples, sd.max_depth = 1920, 1080, 64, 8
     sd.mode = MODE_PATHTRACE
     return sd
+
+
+def pixel_centre_rays(camera: abi.Camera, width: int, height: int, t_min: float = 0.001, t_max: float = 1e9) -> np.ndarray:
+    """One ray per pixel through its centre, [height*width, 8] = (origin, unnormalised direction, t_min, t_max), built as
+    Camera::get_ray builds it (engine/scene.hpp:99-108) for s = (x + 0.5) / W, t = (y + 0.5) / H."""
+    o = np.array(camera.origin[:])
+    llc, hz, vt = np.array(camera.lower_left_corner[:]), np.array(camera.horizontal[:]), np.array(camera.vertical[:])
+    xs, ys = np.meshgrid(np.arange(width), np.arange(height))
+    s = ((xs + 0.5) / width).ravel()
+    t = ((ys + 0.5) / height).ravel()
+    d = ((llc[None] + s[:, None] * hz[None]) + t[:, None] * vt[None]) - o[None]
+    n = width * height
+    return np.concatenate([np.tile(o, (n, 1)), d, np.full((n, 1), t_min), np.full((n, 1), t_max)], axis=1)
+
+
+def stress_rays(n: int, seed: int = 4242, half: float = 11.9) -> np.ndarray:
+    """n incoherent rays for the stress scene, a pure function of (n, seed) computed with + - * only (no library function
+    whose rounding could differ between hosts): origins uniform in [-half, half]^3, unnormalised directions uniform in a cube
+    scaled by a factor in [0.5, 2) (the reference never normalises a ray); tenths of the set have a zero x / y / -0.0 z
+    component, are axis-parallel, or are short (t_max 3); t_min = 0.001."""
+    idx = np.arange(n, dtype=np.uint64)
+    u = [hash_uniform(idx, k, seed) for k in range(7)]
+    org = np.stack([(u[0] * 2.0 - 1.0) * half, (u[1] * 2.0 - 1.0) * half, (u[2] * 2.0 - 1.0) * half], axis=1)
+    d = np.stack([u[3] * 2.0 - 1.0, u[4] * 2.0 - 1.0, u[5] * 2.0 - 1.0], axis=1) * (0.5 + 1.5 * u[6])[:, None]
+    k = n // 10
+    d[0 * k:1 * k, 0] = 0.0
+    d[1 * k:2 * k, 1] = 0.0
+    d[2 * k:3 * k, 2] = -0.0
+    d[3 * k:4 * k, 1:] = 0.0
+    d[3 * k:4 * k, 0] = np.where(d[3 * k:4 * k, 0] == 0.0, 1.0, d[3 * k:4 * k, 0])
+    t_max = np.full(n, 1e9)
+    t_max[4 * k:5 * k] = 3.0
+    return np.concatenate([org, d, np.full((n, 1), 0.001), t_max[:, None]], axis=1)
+
+
+def hit_table_digest(hits: np.ndarray) -> str:
+    """SHA-256 over the canonical closest-hit table of a ray set: per ray (hit, primitive type, primitive index, bits of t),
+    misses as (0, -1, -1, 0).  `hits` is a structured array with the fields of rtx_hit."""
+    import hashlib
+    rec = np.zeros(hits.shape[0], dtype=np.dtype([("hit", "<i4"), ("type", "<i4"), ("index", "<i4"), ("pad", "<i4"), ("t", "<u8")]))
+    h = hits["hit"] != 0
+    rec["hit"] = h
+    rec["type"] = np.where(h, hits["prim_type"], -1)
+    rec["index"] = np.where(h, hits["prim_index"], -1)
+    rec["t"] = np.where(h, np.ascontiguousarray(hits["t"], dtype=np.float64).view(np.uint64), 0)
+    return hashlib.sha256(rec.tobytes()).hexdigest()

@@ -3,7 +3,7 @@
 # Each pass is its own run (counters are not split over passes by the tool) with its own limit.
 set -o pipefail
 OUT=gpurun_out/$1; shift
-ARGS="--steps 2 --warmup 1 --cpu-baseline-seconds 0 $*"
+ARGS="--steps 2 --warmup 1 --cpu-baseline-seconds 0 --no-extras $*"
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }

@@ -21,23 +21,6 @@ def pkg():
     return rtx_pkg.load()
 
 
-@pytest.fixture(scope="session", autouse=True)
-def _torch_device_first(request):
-    """On a GPU box, let torch create its HIP context before the library's first kernel: a few tests hand torch
-    tensors to the library, and torch's lazy initialisation was seen to fail ("No HIP GPUs are available") when it
-    came after a long series of the library's own launches in the same process."""
-    markexpr = request.config.getoption("-m", default="") or ""
-    if "not gpu" in markexpr:
-        return
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-            torch.zeros(1, device="cuda")
-    except Exception:
-        pass
-
-
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_py
@@ -54,6 +37,42 @@ def load_scene(pkg):
             cache[name] = pkg.scene_loader.load(os.path.join(GOLDEN, "scenes", name + ".json"))
         return cache[name]
     return _load
+
+
+C5_TRIANGLES = 10_000_000
+
+
+@pytest.fixture(scope="session")
+def c5(pkg, load_scene):
+    """The synthetic BVH stress configuration at full size (10 M triangles): stress_base.json (the enclosure the reference's own
+    loader read when hits/c5.npz was made) + the seeded triangle soup, with the fixture's two ray sets regenerated from their
+    seeds."""
+    import copy
+    fx = np.load(os.path.join(GOLDEN, "hits", "c5.npz"))
+    assert int(fx["n_triangles"]) == C5_TRIANGLES
+    sd = copy.copy(load_scene("stress_base"))
+    sd._keep = []
+    sd.triangle_array = pkg.synthetic.triangle_soup(C5_TRIANGLES, seed=int(fx["soup_seed"]))
+    W, H = int(fx["width"]), int(fx["height"])
+    cam = sd.camera(W, H)
+    got_cam = np.array([cam.origin[:], cam.lower_left_corner[:], cam.horizontal[:], cam.vertical[:]])
+    assert np.array_equal(got_cam, fx["camera"]), "camera vectors differ from the ones the fixture's pixel rays were made with"
+    rays = {"random": pkg.synthetic.stress_rays(int(fx["n_random"]), seed=int(fx["ray_seed"])),
+            "pixels": pkg.synthetic.pixel_centre_rays(cam, W, H)}
+    return {"scene": sd, "fx": fx, "rays": rays}
+
+
+def record_rate(name, **values):
+    """Append one measured figure (a mismatch rate, a relMSE ...) to gpurun_out/parity_rates.jsonl, from where the numbers the
+    thresholds are set against are copied into profiles/."""
+    import json
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_rates.jsonl"), "a") as f:
+            f.write(json.dumps(dict(name=name, **values)) + "\n")
+    except OSError:
+        pass
 
 
 def soup_scene(pkg, load_scene_fn, base="cornell_box_quad", n=4000):

@@ -284,12 +284,43 @@ def make_bdpt_converged():
         print("converged bdpt", n, "floor", floor, "ref Msamples/s", W * H * 4 * N / secs * 1e-6)
 
 
+def make_c5_fixture(n_triangles=10_000_000, n_random=1_000_000):
+    """hits/c5.npz: the synthetic BVH stress configuration (stress_base.json + synthetic.triangle_soup(10 M, seed 42)) through
+    the real reference's Scene::hit: the digest (synthetic.hit_table_digest) of the closest-hit table of 1 M incoherent rays
+    and of the 1920x1080 pixel-centre rays, plus the first 10 000 records of each verbatim.  The triangles and rays are pure
+    functions of their seeds, so the fixture holds no geometry."""
+    sd = pkg.scene_loader.load(scene_path("stress_base"))
+    soup = pkg.synthetic.triangle_soup(n_triangles, seed=42)
+    cam = sd.camera(1920, 1080)
+    sets = {"random": pkg.synthetic.stress_rays(n_random, seed=4242), "pixels": pkg.synthetic.pixel_centre_rays(cam, 1920, 1080)}
+    out = dict(n_triangles=n_triangles, soup_seed=42, n_random=n_random, ray_seed=4242, width=1920, height=1080,
+               camera=np.array([cam.origin[:], cam.lower_left_corner[:], cam.horizontal[:], cam.vertical[:]]))
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        tp = os.path.join(td, "tris.bin")
+        tris_to_bin(soup).tofile(tp)
+        for name, rays in sets.items():
+            rp, op = os.path.join(td, "rays.bin"), os.path.join(td, "hits.bin")
+            np.ascontiguousarray(rays, dtype=np.float64).tofile(rp)
+            run(["hits", scene_path("stress_base"), rp, op, tp])
+            hits = np.fromfile(op, dtype=HIT_DTYPE)
+            assert len(hits) == len(rays)
+            out[name + "_digest"] = pkg.synthetic.hit_table_digest(hits)
+            out[name + "_first"] = hits[:10000].copy()
+            out[name + "_n_hit"] = int(hits["hit"].sum())
+            out[name + "_n_tri"] = int((hits["prim_type"] == 2).sum())
+            print("c5", name, len(rays), "hit", out[name + "_n_hit"], "triangles", out[name + "_n_tri"], out[name + "_digest"])
+    np.savez_compressed(os.path.join(HERE, "hits", "c5.npz"), **out)
+
+
 def rel_mse(x, r):
     x = np.clip(x, 0.0, 1.0); r = np.clip(r, 0.0, 1.0)   # the film Renderer::render returns is clamped
     return float(np.mean((x - r) ** 2 / (r ** 2 + 1e-2)))
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "c5":   # one fixture only (it takes minutes: the reference builds its 10 M-triangle tree on one thread)
+        make_c5_fixture()
+        return
     if not os.path.exists(REF):
         subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "ref"])
     for sub in ("loader", "hits", "bvh", "films", "converged", "kat"):

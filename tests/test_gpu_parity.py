@@ -6,9 +6,18 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, rel_mse, soup_scene
+from conftest import GOLDEN, record_rate, rel_mse, soup_scene
 
 pytestmark = pytest.mark.gpu
+
+
+PATHPHOTON_F32_BAD_PIXELS_MAX = 0.05
+# Single-precision production walk against the double-precision reference order on the fixture ray sets (pixel centres +
+# random rays with zero components, axis-parallel and short directions): share of rays whose winning primitive differs.
+# Measured per scene on MI355X: profiles/r02_parity_rates.jsonl.
+F32_ID_MISMATCH_MAX = 5e-4
+# Per-channel mean of the converged film against the reference's, relative (the criterion of the survey: 1 %).
+CHANNEL_MEAN_TOL = 0.01
 
 
 def bits(a):
@@ -63,12 +72,13 @@ def test_closest_hit_triangle_soup_bit_exact_vs_reference(pkg, tracer, load_scen
     # single precision: report-level agreement only
     f32 = pt.trace_closest(fx["rays"], pkg.abi.PRECISION_F32)
     agree = (f32["hit"] == fx["hits"]["hit"]) & (f32["prim_type"] == fx["hits"]["prim_type"]) & (f32["prim_index"] == fx["hits"]["prim_index"])
-    assert agree.mean() > 0.995
+    record_rate("f32_id_mismatch_soup", rate=1.0 - float(agree.mean()), rays=int(len(agree)))
+    assert 1.0 - agree.mean() <= F32_ID_MISMATCH_MAX, 1.0 - agree.mean()
     hit = agree & (f32["hit"] == 1)
     assert np.abs(f32["t"][hit] - fx["hits"]["t"][hit]).max() < 1e-3 * (1 + np.abs(fx["hits"]["t"][hit]).max())
 
 
-@pytest.mark.parametrize("name", ["cornell_box", "kitchen_sink", "textured"])
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "demo", "kitchen_sink", "textured", "disk_room", "normal_mapped"])
 def test_fast_path_closest_hit_agreement(name, pkg, tracer, load_scene):
     fx = np.load(os.path.join(GOLDEN, "hits", name + ".npz"))
     pt = tracer(load_scene(name))
@@ -76,7 +86,8 @@ def test_fast_path_closest_hit_agreement(name, pkg, tracer, load_scene):
     check_hits_exact(f64, fx["hits"])
     f32 = pt.trace_closest(fx["rays"], pkg.abi.PRECISION_F32)
     agree = (f32["hit"] == fx["hits"]["hit"]) & (f32["prim_type"] == fx["hits"]["prim_type"]) & (f32["prim_index"] == fx["hits"]["prim_index"])
-    assert agree.mean() > 0.995, agree.mean()
+    record_rate("f32_id_mismatch_" + name, rate=1.0 - float(agree.mean()), rays=int(len(agree)))
+    assert 1.0 - agree.mean() <= F32_ID_MISMATCH_MAX, 1.0 - agree.mean()
 
 
 def test_edge_cases_empty_and_degenerate(pkg, tracer, load_scene):
@@ -119,7 +130,8 @@ def test_f64_film_equals_oracle(name, nee, mis, pkg, oracle, tracer, load_scene)
 
 
 @pytest.mark.parametrize("name,pipe", [("cornell_box", "fused"), ("cornell_box_quad", "fused"), ("environment_demo", "fused"), ("textured", "fused"),
-                                       ("cornell_box", "wavefront"), ("soup", "wavefront"), ("normal_mapped", "fused"), ("normal_mapped", "wavefront")])
+                                       ("cornell_box", "wavefront"), ("soup", "wavefront"), ("normal_mapped", "fused"), ("normal_mapped", "wavefront"),
+                                       ("sphere_field", "fused"), ("sphere_field", "wavefront")])
 def test_f32_pcg_film_equals_oracle_pcg(name, pipe, pkg, oracle, tracer, load_scene):
     """Single precision draws its samples from the pcg4d block generator (RTX_RNG_AUTO).  The oracle fed by the same
     generator renders the same paths in double precision: films agree to single-precision rounding, apart from the
@@ -180,7 +192,7 @@ def test_whitted_film_equals_oracle(name, pkg, oracle, tracer, load_scene):
 
 
 @pytest.mark.parametrize("name,mis", [("caustics_test", 1), ("cornell_box", 1), ("cornell_box", 0), ("cornell_box_quad", 1), ("kitchen_sink", 1), ("disk_room", 1),
-                                      ("textured", 1), ("kitchen_points", 1), ("soup", 1)])
+                                      ("textured", 1), ("kitchen_points", 1), ("soup", 1), ("sphere_field", 1)])
 def test_bdpt_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
     """RenderMode::BDPT (BDPTIntegrator::Li, engine/bdpt.cpp:71-128; the native mode of caustics_test.json): double precision
     agrees with the oracle on the same counter-based numbers (the oracle equals the real reference bit for bit on 8 seeded
@@ -227,7 +239,8 @@ def test_bdpt_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
                                                         ("textured", 1, 3000, 100, 0.5), ("normal_mapped", 1, 3000, 30, 0.3), ("cornell_box_quad", 1, 2000, 20, 0.2),
                                                         ("cornell_box", 1, 60000, 50, 0.15),   # enough photons for a kd-tree several levels deep above the GPU's buckets
                                                         ("cornell_box", 1, 90000, 40, 0.12),   # not walked, and more bounding boxes than the GPU keeps in LDS
-                                                        ("soup_box", 1, 3000, 30, 0.3)])        # cornell_box + 600 triangles: the instances that walk a BVH with an LDS stack
+                                                        ("soup_box", 1, 3000, 30, 0.3),         # cornell_box + 600 triangles: the instances that walk a BVH with an LDS stack
+                                                        ("sphere_field", 1, 3000, 30, 0.3)])    # 14 spheres: flat render kernel, but the photon pass walks the tree (LDS stack sized from the scene)
 def test_pathphoton_film_equals_oracle(name, nee, photons, k, radius, pkg, oracle, tracer, load_scene, monkeypatch):
     """RenderMode::PathPhoton (engine/renderer.cpp:344-372 photon pass, :844-976 integrator): the GPU traces the caustic photons
     (one lane each, counter-based numbers), the host builds the reference's kd-tree over them, the render gathers the k nearest
@@ -260,11 +273,20 @@ def test_pathphoton_film_equals_oracle(name, nee, photons, k, radius, pkg, oracl
     if name != "cornell_box_quad":   # the photons do contribute
         plain, _ = oracle.OracleScene(sd).render(sd.camera(W, H), sd.settings(**dict(over, caustic_photon_count=0)), oracle.RNG_COUNTER, threads=16)
         assert np.abs(ref - plain).max() > 1e-3
-    ref32, _ = oracle.OracleScene(sd).render(sd.camera(W, H), sd.settings(**over), oracle.RNG_COUNTER_PCG, threads=16)
+    ref32, ost32 = oracle.OracleScene(sd).render(sd.camera(W, H), sd.settings(**over), oracle.RNG_COUNTER_PCG, threads=16)
     pt.set_settings(sd.settings(precision=pkg.abi.PRECISION_F32, **over))
     f32 = pt.render().astype(np.float64)
-    assert pt.last_stats.precision_used == pkg.abi.PRECISION_F32 and pt.last_stats.samples == W * H * spp
+    s32 = pt.last_stats
+    assert s32.precision_used == pkg.abi.PRECISION_F32 and s32.samples == W * H * spp
     assert abs(f32.mean() - ref32.mean()) < 0.05 * (1 + ref32.mean()), (f32.mean(), ref32.mean())
+    if not loose:
+        # per pixel, against the oracle on the same pcg4d numbers: a wrong or incomplete photon map moves most lit pixels,
+        # a rounding flip of one photon's path or of a k-th neighbour only a few
+        assert abs(int(s32.segments) - int(ost32.segments)) <= 0.003 * ost32.segments and abs(int(s32.rays_shadow) - int(ost32.rays_shadow)) <= 0.003 * ost32.rays_shadow
+        assert abs(int(s32.rays_closest) - int(ost32.rays_closest)) <= 0.003 * ost32.rays_closest
+        bad = (np.abs(f32 - ref32) > 2e-3 * (1.0 + np.abs(ref32))).any(axis=2)
+        record_rate("pathphoton_f32_bad_pixels_" + name + f"_{photons}", rate=float(bad.mean()))
+        assert bad.mean() < PATHPHOTON_F32_BAD_PIXELS_MAX, (bad.mean(), np.abs(f32 - ref32).max())
     pt.set_settings(sd.settings(photon_gather_count=129, **{k_: v for k_, v in over.items() if k_ != "photon_gather_count"}))
     with pytest.raises(pkg.abi.RtxError, match="photon_gather_count"):
         pt.render()
@@ -331,7 +353,9 @@ def test_f32_film_within_tolerance_of_reference(name, pkg, tracer, load_scene):
     # (a PathPhoton film keeps the variance of its one photon map however many samples it takes)
     assert rel_mse(film16, ref) <= (1.25 if extra else 0.6) * float(fx["noise_floor_relmse"])
     mg, mr = np.clip(film16, 0, 1).mean(axis=(0, 1)), np.clip(ref, 0, 1).mean(axis=(0, 1))
-    assert np.all(np.abs(mg - mr) / mr < (0.2 if extra else 0.015)), (mg, mr)
+    record_rate("converged_" + name, relmse_mean=float(np.mean(errs)), relmse_max=float(max(errs)), noise_floor=float(fx["noise_floor_relmse"]),
+                relmse_16n=float(rel_mse(film16, ref)), channel_mean_rel_diff=[float(v) for v in (mg - mr) / mr])
+    assert np.all(np.abs(mg - mr) / mr < (0.2 if extra else CHANNEL_MEAN_TOL)), (mg, mr)
 
 
 @pytest.mark.parametrize("mode", ["pathtrace", "whitted", "bdpt", "pathphoton"])
@@ -393,6 +417,7 @@ def test_full_size_properties(pkg, tracer, load_scene):
     # (clamped means do not: a 64x36 pixel averages highlights before the clamp).
     mg = film.astype(np.float64).mean(axis=(0, 1))
     mr = fx["film"].astype(np.float64).mean(axis=(0, 1))
+    record_rate("full_size_cornell_box_unclamped_mean", channel_mean_rel_diff=[float(v) for v in (mg - mr) / mr])
     assert np.all(np.abs(mg - mr) / mr < 0.015), (mg, mr)
     pt.set_settings(sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=500, seed=1234, shard_index=5, shard_count=8))
     part = pt.render()
@@ -453,7 +478,7 @@ def test_error_paths(pkg, load_scene):
 
 
 @pytest.mark.parametrize("force_mode", [None, "0", "1"])
-@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "kitchen_sink", "textured", "soup", "normal_mapped"])
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "kitchen_sink", "textured", "soup", "normal_mapped", "sphere_field"])
 def test_wavefront_pipeline_equals_fused(name, force_mode, pkg, tracer, load_scene, monkeypatch):
     """The queue-based pipeline runs the same per-path arithmetic in the same sample order as the
     fused kernel; only instruction selection (multiply-add fusion) may differ between the two
