@@ -11,11 +11,14 @@ from conftest import GOLDEN, record_rate, rel_mse, soup_scene
 pytestmark = pytest.mark.gpu
 
 
-PATHPHOTON_F32_BAD_PIXELS_MAX = 0.05
+# Single-precision PathPhoton film against the oracle on the same numbers: share of pixels off by more than 2e-3 relative.
+# Measured: 0 to 0.0073 (7 of 960 pixels, sphere_field); a photon map with missing or misplaced photons moves most lit pixels.
+PATHPHOTON_F32_BAD_PIXELS_MAX = 0.015
 # Single-precision production walk against the double-precision reference order on the fixture ray sets (pixel centres +
 # random rays with zero components, axis-parallel and short directions): share of rays whose winning primitive differs.
 # Measured per scene on MI355X: profiles/r02_parity_rates.jsonl.
-F32_ID_MISMATCH_MAX = 5e-4
+# The walk is deterministic, so the bound is the measured count of such rays itself (grazing hits on silhouettes and edges).
+F32_ID_MISMATCH_RAYS = {"normal_mapped": 3, "kitchen_sink": 1, "soup": 1}   # of 4296 (soup: 10096) rays; every other scene: 0
 # Per-channel mean of the converged film against the reference's, relative (the criterion of the survey: 1 %).
 CHANNEL_MEAN_TOL = 0.01
 
@@ -72,8 +75,8 @@ def test_closest_hit_triangle_soup_bit_exact_vs_reference(pkg, tracer, load_scen
     # single precision: report-level agreement only
     f32 = pt.trace_closest(fx["rays"], pkg.abi.PRECISION_F32)
     agree = (f32["hit"] == fx["hits"]["hit"]) & (f32["prim_type"] == fx["hits"]["prim_type"]) & (f32["prim_index"] == fx["hits"]["prim_index"])
-    record_rate("f32_id_mismatch_soup", rate=1.0 - float(agree.mean()), rays=int(len(agree)))
-    assert 1.0 - agree.mean() <= F32_ID_MISMATCH_MAX, 1.0 - agree.mean()
+    record_rate("f32_id_mismatch_soup", rate=1.0 - float(agree.mean()), mismatching=int((~agree).sum()), rays=int(len(agree)))
+    assert int((~agree).sum()) <= F32_ID_MISMATCH_RAYS["soup"], int((~agree).sum())
     hit = agree & (f32["hit"] == 1)
     assert np.abs(f32["t"][hit] - fx["hits"]["t"][hit]).max() < 1e-3 * (1 + np.abs(fx["hits"]["t"][hit]).max())
 
@@ -86,8 +89,8 @@ def test_fast_path_closest_hit_agreement(name, pkg, tracer, load_scene):
     check_hits_exact(f64, fx["hits"])
     f32 = pt.trace_closest(fx["rays"], pkg.abi.PRECISION_F32)
     agree = (f32["hit"] == fx["hits"]["hit"]) & (f32["prim_type"] == fx["hits"]["prim_type"]) & (f32["prim_index"] == fx["hits"]["prim_index"])
-    record_rate("f32_id_mismatch_" + name, rate=1.0 - float(agree.mean()), rays=int(len(agree)))
-    assert 1.0 - agree.mean() <= F32_ID_MISMATCH_MAX, 1.0 - agree.mean()
+    record_rate("f32_id_mismatch_" + name, rate=1.0 - float(agree.mean()), mismatching=int((~agree).sum()), rays=int(len(agree)))
+    assert int((~agree).sum()) <= F32_ID_MISMATCH_RAYS.get(name, 0), int((~agree).sum())
 
 
 def test_edge_cases_empty_and_degenerate(pkg, tracer, load_scene):
@@ -328,7 +331,7 @@ def test_mnee_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
 def test_f32_film_within_tolerance_of_reference(name, pkg, tracer, load_scene):
     """Converged-image criterion: relMSE(GPU @ N spp vs reference @ 4N spp) <= 1.25 x
     relMSE(reference @ N vs reference @ 4N, other seeds), relMSE = mean((x-r)^2 / (r^2 + 0.01)) on
-    the clamped-linear film, and per-channel means within 1.5 %.  relMSE of one N-spp film scatters by 12-20 % from
+    the clamped-linear film, and per-channel means within 1 % (measured: at most 0.45 %, profiles/r02_parity_rates.jsonl).  relMSE of one N-spp film scatters by 12-20 % from
     seed to seed (scripts/rng_quality.py, 64 seeds, either generator), so it is averaged over four seeds here; the
     means are taken from a 16N-spp film, whose own noise is below the reference film's."""
     fx = np.load(os.path.join(GOLDEN, "converged", name + ".npz"))
@@ -418,7 +421,7 @@ def test_full_size_properties(pkg, tracer, load_scene):
     mg = film.astype(np.float64).mean(axis=(0, 1))
     mr = fx["film"].astype(np.float64).mean(axis=(0, 1))
     record_rate("full_size_cornell_box_unclamped_mean", channel_mean_rel_diff=[float(v) for v in (mg - mr) / mr])
-    assert np.all(np.abs(mg - mr) / mr < 0.015), (mg, mr)
+    assert np.all(np.abs(mg - mr) / mr < CHANNEL_MEAN_TOL), (mg, mr)
     pt.set_settings(sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=500, seed=1234, shard_index=5, shard_count=8))
     part = pt.render()
     assert np.array_equal(part, film[5::8])
