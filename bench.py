@@ -239,9 +239,9 @@ def roofline(args, abi, jobs, stats, world):
         r.update({"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "kernel": "wf_extend (closest-hit traversal of the ray queue)",
                   "kernel_ms": ext_s * 1e3, "frame_ms": kern_s * 1e3, "achieved": None, "frac": None, "traffic": None})
         if ext_s > 0 and nodes > 0:
-            alg = nodes * rec_b + prims * info.leaf_prim_bytes
+            alg = nodes * rec_b + prims * info.leaf_bytes
             r.update({"achieved": alg / ext_s / 1e9, "frac": alg / ext_s / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch_set": alg,
-                      "records_per_ray": nodes / rays, "prims_per_ray": prims / rays, "record_bytes": rec_b, "prim_bytes": info.leaf_prim_bytes,
+                      "node_records_per_ray": nodes / rays, "leaf_records_per_ray": prims / rays, "node_record_bytes": rec_b, "leaf_record_bytes": info.leaf_bytes,
                       "grays_per_s_closest_hit": rays / ext_s / 1e9})
         if prof:
             r.update({"traffic": prof.get("hbm_bytes_per_launch"), "lanes_active": prof.get("lanes_active"), "kernel_ms_rocprof": prof.get("kernel_ms_rocprof")})

@@ -156,7 +156,7 @@ typedef struct rtx_stats {
   /* queue-based pipeline only (0 otherwise): the closest-hit traversal kernel of the ray queue */
   double seconds_extend;     /* device time of its launches, summed (HIP events around each) */
   uint64_t nodes_visited;    /* node records it fetched and tested */
-  uint64_t prims_tested;     /* leaf primitives it tested */
+  uint64_t prims_tested;     /* leaf records it fetched and tested */
 } rtx_stats;
 
 /* One closest-hit result: the members of hit_record (core/hit.h:20-29) that identify the
@@ -228,11 +228,13 @@ int rtx_shard_rows(int height, int shard_index, int shard_count);
 
 /* BVH statistics of the uploaded scene (0 when there is no bounded primitive). */
 typedef struct rtx_bvh_info {
-  uint64_t ref_nodes, ref_prims;   /* the reference-order binary tree (validation entry point, tie ranks) */
-  uint64_t wide_nodes, wide_bytes; /* node records of the tree the single-precision integrator walks, and their total size */
+  uint64_t ref_nodes, ref_prims;   /* the reference-order binary tree (validation entry point, double precision, tie ranks) */
+  uint64_t wide_nodes, wide_bytes; /* node records of the eight-wide tree the single-precision integrator walks, and their total size */
   double build_seconds;            /* host time of the reference-order build */
-  uint64_t leaf_prim_bytes;        /* size of one leaf primitive record of that tree */
-  uint64_t reserved_;
+  uint64_t leaf_bytes;             /* size of one leaf record of the eight-wide tree (up to three primitives) */
+  uint64_t wide_leaves;            /* its leaf records */
+  uint64_t wide_levels;            /* its depth in node levels */
+  double wide_build_seconds;       /* time of its build on the GPU */
 } rtx_bvh_info;
 int rtx_get_bvh_info(rtx_ctx* ctx, rtx_bvh_info* out);
 

@@ -101,7 +101,8 @@ class Hit(C.Structure):
 
 class BvhInfo(C.Structure):
     _fields_ = [("ref_nodes", C.c_uint64), ("ref_prims", C.c_uint64), ("wide_nodes", C.c_uint64),
-                ("wide_bytes", C.c_uint64), ("build_seconds", C.c_double), ("leaf_prim_bytes", C.c_uint64), ("reserved_", C.c_uint64)]
+                ("wide_bytes", C.c_uint64), ("build_seconds", C.c_double), ("leaf_bytes", C.c_uint64), ("wide_leaves", C.c_uint64),
+                ("wide_levels", C.c_uint64), ("wide_build_seconds", C.c_double)]
 
 
 assert C.sizeof(Hit) == 96

@@ -87,9 +87,9 @@ void launch_film_reduce(const float* partial, float* film, unsigned long long np
   hipLaunchKernelGGL(film_reduce_kernel<float>, dim3(grid), dim3(256), 0, stream, partial, film, npix, n_chunks, spp);
 }
 
-int launch_trace_fast(const DScene<float>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream) {
+int launch_trace_fast(const DScene<float>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream, int n_cus) {
   if (n == 0) return 0;
-  unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+  unsigned grid = trace_fast_grid(n, n_cus);
   if (mode == MODE_FLAT)
     hipLaunchKernelGGL((trace_fast_kernel<float, MODE_FLAT>), dim3(grid), dim3(kBlock), lds_bytes, stream, sc, rays8, n, out);
   else

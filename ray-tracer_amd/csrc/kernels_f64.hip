@@ -119,10 +119,10 @@ void launch_film_reduce(const double* partial, float* film, unsigned long long n
   hipLaunchKernelGGL(film_reduce_kernel<double>, dim3(grid), dim3(256), 0, stream, partial, film, npix, n_chunks, spp);
 }
 
-int launch_trace_fast(const DScene<double>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream) {
+int launch_trace_fast(const DScene<double>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream, int n_cus) {
   if (n == 0) return 0;
   if (mode == MODE_FLAT) return -1;
-  unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+  unsigned grid = trace_fast_grid(n, n_cus);
   hipLaunchKernelGGL((trace_fast_kernel<double, MODE_TREE_UV>), dim3(grid), dim3(kBlock), lds_bytes, stream, sc, rays8, n, out);
   return 0;
 }

@@ -377,7 +377,7 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
         R er = slab_entry(rr, r, inv, t_min, c.t, ok_r);
         if (ok_l && ok_r) {
           int near = el <= er ? node + 1 : nd.a, far = el <= er ? nd.a : node + 1;
-          if (sp < st.limit) st.at(sp++) = far;
+          st.push(sp, far);
           node = near; descend = true;
         } else if (ok_l) { node = node + 1; descend = true; }
         else if (ok_r) { node = nd.a; descend = true; }
@@ -385,89 +385,161 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
     }
     if (!descend) {
       if (sp == 0) break;
-      node = st.at(--sp);
+      node = st.pop(sp);
     }
   }
   return c.type >= 0;
 }
 
-// Single-precision walk over the child-pair records: one 64-byte fetch per step, nearer child
-// first, farther child on the LDS stack, leaves tested as soon as their box is hit.
-// On an exact tie in t the primitive later in the reference's leaf order wins, whatever the
-// visiting order (`rank` = position in that order).
-RTX_DEV bool pair_slab(const float* lo, const float* hi, const Ray<float>& r, V3<float> inv, float t_min, float t_max, float& entry) {
-  float t0 = (lo[0] - r.o.x) * inv.x, t1 = (hi[0] - r.o.x) * inv.x;
-  float a = fminf(t0, t1), b = fmaxf(t0, t1);
-  t0 = (lo[1] - r.o.y) * inv.y; t1 = (hi[1] - r.o.y) * inv.y;
-  a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
-  t0 = (lo[2] - r.o.z) * inv.z; t1 = (hi[2] - r.o.z) * inv.z;
-  a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
-  a = fmaxf(a, t_min); b = fminf(b, t_max);
-  entry = a;
-  return a < b;
-}
+// ------------------------------------------------------------------------------------------
+// Single-precision walk over the eight-wide tree (DNode8 / DLeaf3, pt_types.hpp), cut into resumable steps so that the
+// lanes of a persistent kernel can pick up a new ray when theirs is finished.
+//   walk8_inner  fetches ONE node record (a 128-byte line), tests its eight quantised boxes, continues with the nearest
+//                child entered and parks the others on the stack, farthest first (closest hit) or in slot order (any hit);
+//   walk8_leaf   fetches ONE leaf record (a 128-byte line) and tests its up to three triangles (spheres and boxes through
+//                their tables).
+// w.node is a node (>= 0), a leaf code ~leaf (< 0) or kWalkDone.  A parked entry is not re-tested against the interval the
+// hits found meanwhile have shortened (its children / primitives are).  A box is entered on a <= b: the tree's own grouping
+// may make a box flat along an axis, which must not hide its primitives.  On an exact tie in t the primitive later in the
+// reference's leaf order wins, whatever the visiting order (DScene::rank; best_p = the current winner's primitive number).
+// ------------------------------------------------------------------------------------------
+struct Walk8 { V3<float> inv; int node, sp, best_p; };
 
-template <bool ANY> RTX_DEV void pair_leaf(const DScene<float>& sc, int code, const Ray<float>& r, float t_min, Cand<float>& c, int& rank) {
-  const int first = (~code) >> 2, count = (~code) & 3;
-  for (int i = 0; i < count; ++i) {
-    const int pos = first + i;
-    const DLeafPrim lp = sc.leaf_prims[pos];
-    float t, u, v;
-    bool ok = false;
-    if (lp.type == PRIM_TRIANGLE) {
-      V3<float> v0 = mk3(lp.v0);
-      V3<float> e1 = mk3(lp.v1) - v0, e2 = mk3(lp.v2) - v0;
-      V3<float> h = cross(r.d, e2);
-      float a = dot(e1, h);
-      float f = 1.0f / a;
-      V3<float> s = r.o - v0;
-      u = f * dot(s, h);
-      V3<float> q = cross(s, e1);
-      v = f * dot(r.d, q);
-      t = f * dot(e2, q);
-      ok = fabsf(a) >= 1e-8f && u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= t_min && t <= c.t;
-      ok = ok && !(t == c.t && pos < rank);
-      if (ok) { c.t = t; c.type = PRIM_TRIANGLE; c.idx = lp.index; c.uv_kind = 1; c.ua = u; c.ub = v; rank = pos; }
-    } else {
-      Cand<float> trial = c;
-      test_bounded(sc, lp.type, lp.index, r, t_min, trial);
-      const bool changed = trial.type == lp.type && trial.idx == lp.index && (trial.t != c.t || c.type != lp.type || c.idx != lp.index);
-      if (changed && !(trial.t == c.t && pos < rank)) { c = trial; rank = pos; }
-    }
+RTX_DEV void walk8_begin(Walk8& w, const Ray<float>& r) {
+  // the quantised boxes multiply 1/d by box units: keep it finite (a direction component below 1e-18 moves the ray by less
+  // than 1e-9 over the longest ray, so the slab of that axis is constant along it either way)
+  w.inv = {fminf(fmaxf(1.0f / r.d.x, -1e18f), 1e18f), fminf(fmaxf(1.0f / r.d.y, -1e18f), 1e18f), fminf(fmaxf(1.0f / r.d.z, -1e18f), 1e18f)};
+  w.node = 0; w.sp = 0; w.best_p = -1;
+}
+RTX_DEV bool walk8_at_inner(const Walk8& w) { return w.node >= 0 && w.node != kWalkDone; }
+RTX_DEV bool walk8_at_leaf(const Walk8& w) { return w.node < 0; }
+
+RTX_DEV uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
+RTX_DEV uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+template <bool SORT> RTX_DEV void walk8_inner(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_best, Walk8& w, LaneStack st) {
+  const uint4* rec = reinterpret_cast<const uint4*>(sc.nodes8 + w.node);
+  const uint4 h0 = rec[0], h1 = rec[1], h2 = rec[2], h3 = rec[3];
+  const uint2 h4 = *reinterpret_cast<const uint2*>(rec + 4);
+  const uint32_t exps = h0.w;
+  // slab distance of a quantised plane q:  (org + q * unit - o) / d  =  q * (unit / d) + (org - o) / d
+  const float ax = __uint_as_float((exps & 0xffu) << 23) * w.inv.x, ay = __uint_as_float(((exps >> 8) & 0xffu) << 23) * w.inv.y,
+              az = __uint_as_float(((exps >> 16) & 0xffu) << 23) * w.inv.z;
+  const float bx = (__uint_as_float(h0.x) - r.o.x) * w.inv.x, by = (__uint_as_float(h0.y) - r.o.y) * w.inv.y, bz = (__uint_as_float(h0.z) - r.o.z) * w.inv.z;
+  const uint32_t qlx[2] = {h1.x, h1.y}, qly[2] = {h1.z, h1.w}, qlz[2] = {h2.x, h2.y};
+  const uint32_t qhx[2] = {h2.z, h2.w}, qhy[2] = {h3.x, h3.y}, qhz[2] = {h3.z, h3.w};
+  const int n_inner = (int)((exps >> 24) & 15u);
+  const int inner_base = (int)h4.x, leaf_base = (int)h4.y - n_inner;   // child k >= n_inner is leaf leaf_base + k
+  uint32_t key[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int sh = 8 * (k & 3);
+    float t0 = fmaf((float)((qlx[k >> 2] >> sh) & 0xffu), ax, bx), t1 = fmaf((float)((qhx[k >> 2] >> sh) & 0xffu), ax, bx);
+    float a = fminf(t0, t1), b = fmaxf(t0, t1);
+    t0 = fmaf((float)((qly[k >> 2] >> sh) & 0xffu), ay, by); t1 = fmaf((float)((qhy[k >> 2] >> sh) & 0xffu), ay, by);
+    a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
+    t0 = fmaf((float)((qlz[k >> 2] >> sh) & 0xffu), az, bz); t1 = fmaf((float)((qhz[k >> 2] >> sh) & 0xffu), az, bz);
+    a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
+    a = fmaxf(a, t_min); b = fminf(b, t_best);
+    // an unused slot holds the planes (255, 0): a > b on every axis with a non-zero extent; the slot test covers flat nodes
+    const bool ok = a <= b && (((qlx[k >> 2] >> sh) & 0xffu) != 255u || ((qhx[k >> 2] >> sh) & 0xffu) != 0u);
+    // sortable key: the entry distance (a positive float, whose bit pattern orders as an unsigned integer) with the slot in
+    // its three lowest bits
+    key[k] = ok ? ((__float_as_uint(a) & ~7u) | (uint32_t)k) : 0xffffffffu;
+  }
+  auto code = [&](uint32_t kk) -> int {
+    const int k = (int)(kk & 7u);
+    return k < n_inner ? inner_base + k : ~(leaf_base + k);
+  };
+  if (SORT) {
+    // sorting network on the keys, ascending (19 compare-exchanges of one min and one max each)
+#define RTX_CX(i, j) { const uint32_t lo_ = umin_(key[i], key[j]); key[j] = umax_(key[i], key[j]); key[i] = lo_; }
+    RTX_CX(0, 1) RTX_CX(2, 3) RTX_CX(4, 5) RTX_CX(6, 7)
+    RTX_CX(0, 2) RTX_CX(1, 3) RTX_CX(4, 6) RTX_CX(5, 7)
+    RTX_CX(1, 2) RTX_CX(5, 6) RTX_CX(0, 4) RTX_CX(3, 7)
+    RTX_CX(1, 5) RTX_CX(2, 6)
+    RTX_CX(1, 4) RTX_CX(3, 6)
+    RTX_CX(2, 4) RTX_CX(3, 5)
+    RTX_CX(3, 4)
+#undef RTX_CX
+#pragma unroll
+    for (int j = 7; j >= 1; --j)
+      if (key[j] != 0xffffffffu) st.push(w.sp, code(key[j]));
+    int go = key[0] != 0xffffffffu ? code(key[0]) : kWalkDone;
+    if (go == kWalkDone && w.sp > 0) go = st.pop(w.sp);
+    w.node = go;
+  } else {
+    int go = kWalkDone;
+#pragma unroll
+    for (int j = 7; j >= 0; --j)
+      if (key[j] != 0xffffffffu) {
+        if (go != kWalkDone) st.push(w.sp, go);
+        go = code(key[j]);
+      }
+    if (go == kWalkDone && w.sp > 0) go = st.pop(w.sp);
+    w.node = go;
   }
 }
 
-template <bool ANY> RTX_DEV bool walk_pairs(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, LaneStack st) {
-  const V3<float> inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
-  int sp = 0, node = 0, rank = -1;
+// Möller-Trumbore on in-place vertices (ref: engine/primitives.hpp:78-110); NaN vertices fail the first comparison.
+RTX_DEV bool leaf_tri_t(const float* v, const Ray<float>& r, float t_min, float t_max, float& t, float& u, float& vv) {
+  const V3<float> v0 = {v[0], v[1], v[2]};
+  const V3<float> e1 = V3<float>{v[3], v[4], v[5]} - v0, e2 = V3<float>{v[6], v[7], v[8]} - v0;
+  const V3<float> h = cross(r.d, e2);
+  const float a = dot(e1, h);
+  const float f = 1.0f / a;
+  const V3<float> s = r.o - v0;
+  u = f * dot(s, h);
+  const V3<float> q = cross(s, e1);
+  vv = f * dot(r.d, q);
+  t = f * dot(e2, q);
+  return fabsf(a) >= 1e-8f && u >= 0.f && u <= 1.f && vv >= 0.f && u + vv <= 1.f && t >= t_min && t <= t_max;
+}
+
+template <bool ANY> RTX_DEV void walk8_leaf(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, Walk8& w, LaneStack st) {
+  const DLeaf3* lf = sc.leaves3 + (~w.node);
+  const uint4* rec = reinterpret_cast<const uint4*>(lf);
+  uint4 q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] = rec[i];
+  const float* v = reinterpret_cast<const float*>(q);
+  const int* tail = reinterpret_cast<const int*>(q) + 27;   // id[3], count, other
+#pragma unroll
+  for (int k = 0; k < kLeafMaxPrims; ++k) {
+    float t, u, vv;
+    bool ok = leaf_tri_t(v + 9 * k, r, t_min, c.t, t, u, vv);
+    const int p = tail[k];
+    if (ok && t == c.t && w.best_p >= 0) ok = sc.rank[p] > sc.rank[w.best_p];   // exact tie: the later one in the reference's order wins
+    if (ok) { c.t = t; c.type = PRIM_TRIANGLE; c.idx = p - sc.n_spheres; c.uv_kind = 1; c.ua = u; c.ub = vv; w.best_p = p; }
+  }
+  uint32_t other = (uint32_t)tail[4];
+  while (other) {   // spheres and boxes: rare in a tree of triangles
+    const int k = __ffs((int)other) - 1;
+    other &= other - 1u;
+    const int p = k == 0 ? tail[0] : (k == 1 ? tail[1] : tail[2]);   // (no run-time index into the record: it stays in registers)
+    const int type = p < sc.n_spheres ? PRIM_SPHERE : PRIM_BOX;
+    const int idx = p < sc.n_spheres ? p : p - sc.n_spheres - sc.n_tris;
+    Cand<float> trial = c;
+    test_bounded(sc, type, idx, r, t_min, trial);
+    const bool changed = trial.type == type && trial.idx == idx && (trial.t != c.t || c.type != type || c.idx != idx);
+    if (changed && !(trial.t == c.t && w.best_p >= 0 && sc.rank[p] < sc.rank[w.best_p])) { c = trial; w.best_p = p; }
+  }
+  if (ANY && c.type >= 0) { w.node = kWalkDone; return; }
+  w.node = w.sp > 0 ? st.pop(w.sp) : kWalkDone;
+}
+
+template <bool ANY> RTX_DEV bool walk8(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, LaneStack st) {
+  Walk8 w;
+  walk8_begin(w, r);
 #ifdef RTX_WALK_STATS
   int walk_steps = 0;   // diagnostic build: steps per ray come back in hit.u
 #endif
-  for (;;) {
+  while (w.node != kWalkDone) {
 #ifdef RTX_WALK_STATS
     ++walk_steps;
 #endif
-    const DNodePair p = sc.pairs[node];
-    float el, er;
-    const bool ok_l = pair_slab(p.lo_l, p.hi_l, r, inv, t_min, c.t, el);
-    const bool ok_r = pair_slab(p.lo_r, p.hi_r, r, inv, t_min, c.t, er);
-    const bool swap = ok_l && ok_r && er < el;
-    const int near = swap ? p.cr : p.cl, far = swap ? p.cl : p.cr;
-    const bool ok_near = swap ? ok_r : ok_l, ok_far = swap ? ok_l : ok_r;
-    const float e_far = swap ? el : er;
-    int go = 0x7fffffff;   // inner node to descend into
-    if (ok_near) {
-      if (near < 0) { pair_leaf<ANY>(sc, near, r, t_min, c, rank); if (ANY && c.type >= 0) return true; }
-      else go = near;
-    }
-    if (ok_far && e_far < c.t) {
-      if (far < 0) { pair_leaf<ANY>(sc, far, r, t_min, c, rank); if (ANY && c.type >= 0) return true; }
-      else if (go == 0x7fffffff) go = far;
-      else if (sp < st.limit) st.at(sp++) = far;
-    }
-    if (go != 0x7fffffff) { node = go; continue; }
-    if (sp == 0) break;
-    node = st.at(--sp);
+    if (w.node >= 0) walk8_inner<!ANY>(sc, r, t_min, c.t, w, st);
+    else { walk8_leaf<ANY>(sc, r, t_min, c, w, st); if (ANY && c.type >= 0) return true; }
   }
 #ifdef RTX_WALK_STATS
   c.ua = (float)walk_steps; c.uv_kind = 1;
@@ -475,92 +547,9 @@ template <bool ANY> RTX_DEV bool walk_pairs(const DScene<float>& sc, const Ray<f
   return c.type >= 0;
 }
 
-// The same walk cut into resumable steps, for persistent kernels whose lanes pick up a new ray
-// when theirs is finished.  w.node is an inner pair (>= 0), a leaf code (< 0) or kWalkDone.
-// pair_walk_inner fetches one child pair; pair_walk_leaf tests ONE primitive of the leaf, so
-// every lane of a wave that is in the same phase executes the same instructions.  The kernels
-// run the leaf phase only when enough lanes have a leaf pending (it is the longer of the two
-// and would otherwise run for a handful of lanes on every trip).  The farther child goes on
-// the stack whether it is an inner node or a leaf; a popped entry is not re-tested against the
-// shrunken interval (its children / primitives are).
-struct PairWalk { V3<float> inv; int node, sp, rank; };
-constexpr int kWalkDone = 0x7fffffff;
-
-RTX_DEV void pair_walk_begin(PairWalk& w, const Ray<float>& r) {
-  w.inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
-#if RTX_WIDE_QUANT
-  // the quantised records multiply 1/d by box units: keep it finite (a component below 1e-18 moves the ray by less
-  // than 1e-9 over the longest ray, so the slab of that axis is constant along it either way)
-  w.inv = {fminf(fmaxf(w.inv.x, -1e18f), 1e18f), fminf(fmaxf(w.inv.y, -1e18f), 1e18f), fminf(fmaxf(w.inv.z, -1e18f), 1e18f)};
-#endif
-  w.node = 0; w.sp = 0; w.rank = -1;
-}
-RTX_DEV bool pair_walk_at_inner(const PairWalk& w) { return w.node >= 0 && w.node != kWalkDone; }
-RTX_DEV bool pair_walk_at_leaf(const PairWalk& w) { return w.node < 0; }
-
-// One four-wide record: test the (up to) four boxes, continue with the nearest child that was
-// entered and park the others on the stack, farthest first.
-RTX_DEV void pair_walk_inner(const DScene<float>& sc, const Ray<float>& r, float t_min, const Cand<float>& c, PairWalk& w, LaneStack st) {
-  float e[4]; int ch[4];
-#if RTX_WIDE_QUANT
-  const DNodeWideQ q = sc.wideq[w.node];
-  // slab distance of a quantised plane v:  (org + v * unit - o) / d  =  v * (unit / d) + (org - o) / d
-  const float ux = __uint_as_float((q.exps & 0xffu) << 23), uy = __uint_as_float(((q.exps >> 8) & 0xffu) << 23), uz = __uint_as_float(((q.exps >> 16) & 0xffu) << 23);
-  const float ax = ux * w.inv.x, ay = uy * w.inv.y, az = uz * w.inv.z;
-  const float bx = (q.org[0] - r.o.x) * w.inv.x, by = (q.org[1] - r.o.y) * w.inv.y, bz = (q.org[2] - r.o.z) * w.inv.z;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float t0 = fmaf((float)((q.qlo[0] >> (8 * k)) & 0xffu), ax, bx), t1 = fmaf((float)((q.qhi[0] >> (8 * k)) & 0xffu), ax, bx);
-    float a = fminf(t0, t1), b = fmaxf(t0, t1);
-    t0 = fmaf((float)((q.qlo[1] >> (8 * k)) & 0xffu), ay, by); t1 = fmaf((float)((q.qhi[1] >> (8 * k)) & 0xffu), ay, by);
-    a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
-    t0 = fmaf((float)((q.qlo[2] >> (8 * k)) & 0xffu), az, bz); t1 = fmaf((float)((q.qhi[2] >> (8 * k)) & 0xffu), az, bz);
-    a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
-    a = fmaxf(a, t_min); b = fminf(b, c.t);
-    const bool ok = a < b && q.child[k] != kWideEmpty;
-    e[k] = ok ? a : 3.0e38f;
-    ch[k] = ok ? q.child[k] : kWalkDone;
-  }
-#else
-  const DNodeWide q = sc.wide[w.node];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float t0 = (q.lo_x[k] - r.o.x) * w.inv.x, t1 = (q.hi_x[k] - r.o.x) * w.inv.x;
-    float a = fminf(t0, t1), b = fmaxf(t0, t1);
-    t0 = (q.lo_y[k] - r.o.y) * w.inv.y; t1 = (q.hi_y[k] - r.o.y) * w.inv.y;
-    a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
-    t0 = (q.lo_z[k] - r.o.z) * w.inv.z; t1 = (q.hi_z[k] - r.o.z) * w.inv.z;
-    a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
-    a = fmaxf(a, t_min); b = fminf(b, c.t);
-    const bool ok = a < b && q.child[k] != kWideEmpty;
-    e[k] = ok ? a : 3.0e38f;
-    ch[k] = ok ? q.child[k] : kWalkDone;
-  }
-#endif
-  // sorting network on (entry distance, child): ascending
-#define RTX_CSWAP(i, j) { const bool s_ = e[j] < e[i]; const float te = s_ ? e[j] : e[i]; const float tf = s_ ? e[i] : e[j]; \
-                          const int tc = s_ ? ch[j] : ch[i]; const int td = s_ ? ch[i] : ch[j]; e[i] = te; e[j] = tf; ch[i] = tc; ch[j] = td; }
-  RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
-#undef RTX_CSWAP
-  if (ch[3] != kWalkDone) st.push(w.sp, ch[3]);
-  if (ch[2] != kWalkDone) st.push(w.sp, ch[2]);
-  if (ch[1] != kWalkDone) st.push(w.sp, ch[1]);
-  int go = ch[0];
-  if (go == kWalkDone && w.sp > 0) go = st.pop(w.sp);
-  w.node = go;
-}
-
-template <bool ANY> RTX_DEV void pair_walk_leaf(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, PairWalk& w, LaneStack st) {
-  const int first = (~w.node) >> 2, count = (~w.node) & 3;
-  pair_leaf<ANY>(sc, ~((first << 2) | 1), r, t_min, c, w.rank);
-  if (ANY && c.type >= 0) { w.node = kWalkDone; return; }
-  if (count > 1) w.node = ~(((first + 1) << 2) | (count - 1));
-  else w.node = w.sp > 0 ? st.pop(w.sp) : kWalkDone;
-}
-
 template <class R, bool ANY> RTX_DEV bool walk_tree(const DScene<R>& sc, const Ray<R>& r, R t_min, Cand<R>& c, LaneStack st) {
   if constexpr (std::is_same<R, float>::value) {
-    if (sc.n_prims > kLinearMaxPrims) return walk_pairs<ANY>(sc, r, t_min, c, st);
+    if (sc.n_prims > kLinearMaxPrims) return walk8<ANY>(sc, r, t_min, c, st);
   }
   return walk_bounded<R, ANY>(sc, r, t_min, c, st);
 }

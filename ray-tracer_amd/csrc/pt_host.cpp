@@ -222,155 +222,19 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
     cp3(mats[i].c1, m.tex_color1); cp3(mats[i].c2, m.tex_color2); mats[i].scale = (R)m.tex_scale;
     mats[i].nmap_image = m.has_normal_map ? m.normal_image : -1; mats[i].pad = 0; mats[i].nmap_strength = (R)m.normal_strength;
   }
-  // Production BVH: the reference tree's topology, boxes in R.  Float boxes are rounded
-  // outward; a box that is flat in double stays flat so that the strict slab test rejects it
-  // exactly as the reference's does (a leaf of axis-aligned coplanar triangles is never hit there).
-  Staging<DNode2<R>> nodes(bvh.nodes.size());
-  parallel_for(bvh.nodes.size(), [&](size_t b, size_t e) {
-    for (size_t i = b; i < e; ++i) {
-      const DNodeRef& n = bvh.nodes[i];
-      for (int a = 0; a < 3; ++a) {
-        if (std::is_same<R, float>::value && n.lo[a] != n.hi[a]) { nodes[i].lo[a] = (R)f_down(n.lo[a]); nodes[i].hi[a] = (R)f_up(n.hi[a]); }
-        else { nodes[i].lo[a] = (R)n.lo[a]; nodes[i].hi[a] = (R)n.hi[a]; }
-      }
-      if (n.count > 0) { nodes[i].a = n.first; nodes[i].count = n.count; }
-      else { nodes[i].a = n.right; nodes[i].count = 0; }
-    }
-  });
-  if (std::is_same<R, float>::value && bvh.prims.size() > (size_t)kLinearMaxPrims) {
-    // child-pair records, one per inner node, in the order the inner nodes appear in preorder
-    Staging<int32_t> pair_of(bvh.nodes.size());   // read for inner nodes only
-    int32_t np = 0;
-    for (size_t i = 0; i < bvh.nodes.size(); ++i) if (bvh.nodes[i].count == 0) pair_of[i] = np++;
-    Staging<DNodePair> pairs((size_t)np);
-    auto code = [&](int32_t child) -> int32_t {
-      const DNodeRef& c = bvh.nodes[child];
-      return c.count > 0 ? ~((c.first << 2) | c.count) : pair_of[child];
-    };
-    auto box = [&](int32_t child, float* lo, float* hi) {
-      const DNodeRef& c = bvh.nodes[child];
-      for (int a = 0; a < 3; ++a) {
-        if (c.lo[a] != c.hi[a]) { lo[a] = f_down(c.lo[a]); hi[a] = f_up(c.hi[a]); }
-        else { lo[a] = (float)c.lo[a]; hi[a] = (float)c.hi[a]; }
-      }
-    };
+  // Double precision walks the reference tree's topology (left child = i + 1), so that closest hits keep the reference's bits
+  // whatever the visiting order.  Single precision walks the eight-wide tree built on the GPU (HostScene::upload).
+  Staging<DNode2<R>> nodes;
+  if constexpr (std::is_same<R, double>::value) {
+    nodes.resize(bvh.nodes.size());
     parallel_for(bvh.nodes.size(), [&](size_t b, size_t e) {
       for (size_t i = b; i < e; ++i) {
         const DNodeRef& n = bvh.nodes[i];
-        if (n.count > 0) continue;
-        DNodePair& p = pairs[(size_t)pair_of[i]];
-        box(n.left, p.lo_l, p.hi_l); box(n.right, p.lo_r, p.hi_r);
-        p.cl = code(n.left); p.cr = code(n.right); p.pad0 = p.pad1 = 0;
+        for (int a = 0; a < 3; ++a) { nodes[i].lo[a] = n.lo[a]; nodes[i].hi[a] = n.hi[a]; }
+        if (n.count > 0) { nodes[i].a = n.first; nodes[i].count = n.count; }
+        else { nodes[i].a = n.right; nodes[i].count = 0; }
       }
     });
-    Staging<DLeafPrim> leaf(bvh.prims.size());
-    parallel_for(bvh.prims.size(), [&](size_t b, size_t e) {
-      for (size_t i = b; i < e; ++i) {
-        DLeafPrim& l = leaf[i];
-        memset(&l, 0, sizeof l);
-        l.type = bvh.prims[i].type; l.index = bvh.prims[i].index;
-        if (l.type == PRIM_TRIANGLE) {
-          const rtx_triangle& t = d.triangles[l.index];
-          cp3(l.v0, t.v0); cp3(l.v1, t.v1); cp3(l.v2, t.v2); l.mat = t.material_id;
-        }
-      }
-    });
-    sc.pairs = push(pool, pairs, ok); sc.leaf_prims = push(pool, leaf, ok); sc.n_pairs = np;
-    // four-wide records: an inner node's children, each replaced by ITS children when it is inner
-    // An inner node at even depth starts a wide record.  The nodes are in preorder, so one forward pass hands the depth
-    // parity down and numbers the records.
-    Staging<int32_t> wide_of(bvh.nodes.size());
-    std::vector<int32_t> wide_nodes;   // binary node of every wide record, in record order
-    {
-      Staging<uint8_t> odd(bvh.nodes.size());
-      odd[0] = 0;
-      wide_nodes.reserve(bvh.nodes.size() / 6 + 16);
-      for (size_t i = 0; i < bvh.nodes.size(); ++i) {
-        const DNodeRef& n = bvh.nodes[i];
-        if (n.count > 0) continue;
-        if (!odd[i]) { wide_of[i] = (int32_t)wide_nodes.size(); wide_nodes.push_back((int32_t)i); }
-        odd[(size_t)n.left] = odd[(size_t)n.right] = (uint8_t)(odd[i] ^ 1);
-      }
-    }
-#if RTX_WIDE_QUANT
-    Staging<DNodeWideQ> wideq(wide_nodes.size());
-    parallel_for(wide_nodes.size(), [&](size_t wb, size_t we) {
-    for (size_t w = wb; w < we; ++w) {
-      DNodeWideQ& q = wideq[w];
-      memset(&q, 0, sizeof q);
-      float lo[4][3], hi[4][3];
-      int32_t kid[4];
-      int used = 0;
-      auto add = [&](int32_t node) {
-        const DNodeRef& c = bvh.nodes[(size_t)node];
-        box(node, lo[used], hi[used]);
-        const bool flat = c.lo[0] == c.hi[0] || c.lo[1] == c.hi[1] || c.lo[2] == c.hi[2];
-        kid[used] = flat ? kWideEmpty : (c.count > 0 ? ~((c.first << 2) | c.count) : wide_of[(size_t)node]);
-        ++used;
-      };
-      const DNodeRef& n = bvh.nodes[(size_t)wide_nodes[w]];
-      const int32_t kids[2] = {n.left, n.right};
-      for (int32_t k : kids) {
-        const DNodeRef& c = bvh.nodes[(size_t)k];
-        if (c.count > 0) add(k);
-        else { add(c.left); add(c.right); }
-      }
-      for (int k = 0; k < 4; ++k) q.child[k] = k < used ? kid[k] : kWideEmpty;
-      for (int a = 0; a < 3; ++a) {
-        float plo = INFINITY, phi = -INFINITY;
-        for (int k = 0; k < used; ++k) if (kid[k] != kWideEmpty) { plo = std::fmin(plo, lo[k][a]); phi = std::fmax(phi, hi[k][a]); }
-        if (!(plo <= phi)) { plo = 0.f; phi = 0.f; }   // no live child
-        q.org[a] = plo;
-        // unit 2^e with 255 units covering the extent; the loop settles what float rounding leaves open
-        int e = -126;
-        const double ext = (double)phi - (double)plo;
-        if (ext > 0.0) { (void)std::frexp(ext / 255.0, &e); if (e < -126) e = -126; }
-        while (e < 127 && std::ceil(ext / std::ldexp(1.0, e)) > 255.0) ++e;
-        const double unit = std::ldexp(1.0, e);
-        q.exps |= (uint32_t)(e + 127) << (8 * a);
-        uint32_t ql = 0, qh = 0;
-        for (int k = 0; k < 4; ++k) {
-          int l = 255, h = 0;   // an empty child: inverted, never entered
-          if (k < used && kid[k] != kWideEmpty) {
-            l = (int)std::floor(((double)lo[k][a] - (double)plo) / unit);
-            h = (int)std::ceil(((double)hi[k][a] - (double)plo) / unit);
-            l = l < 0 ? 0 : l; h = h > 255 ? 255 : h;
-          }
-          ql |= (uint32_t)l << (8 * k); qh |= (uint32_t)h << (8 * k);
-        }
-        q.qlo[a] = ql; q.qhi[a] = qh;
-      }
-    }
-    });
-    sc.wideq = push(pool, wideq, ok); sc.n_wide = (int32_t)wideq.size();
-#else
-    Staging<DNodeWide> wide(wide_nodes.size());
-    parallel_for(wide_nodes.size(), [&](size_t wb, size_t we) {
-    for (size_t w = wb; w < we; ++w) {
-      DNodeWide& q = wide[w];
-      memset(&q, 0, sizeof q);
-      for (int k = 0; k < 4; ++k) q.child[k] = kWideEmpty;
-      int used = 0;
-      auto add = [&](int32_t node) {
-        const DNodeRef& c = bvh.nodes[(size_t)node];
-        float lo[3], hi[3];
-        box(node, lo, hi);
-        q.lo_x[used] = lo[0]; q.lo_y[used] = lo[1]; q.lo_z[used] = lo[2];
-        q.hi_x[used] = hi[0]; q.hi_y[used] = hi[1]; q.hi_z[used] = hi[2];
-        q.child[used] = c.count > 0 ? ~((c.first << 2) | c.count) : wide_of[(size_t)node];
-        ++used;
-      };
-      const DNodeRef& n = bvh.nodes[(size_t)wide_nodes[w]];
-      const int32_t kids[2] = {n.left, n.right};
-      for (int32_t k : kids) {
-        const DNodeRef& c = bvh.nodes[(size_t)k];
-        if (c.count > 0) add(k);
-        else { add(c.left); add(c.right); }
-      }
-    }
-    });
-    sc.wide = push(pool, wide, ok); sc.n_wide = (int32_t)wide.size();
-#endif
   }
   if (std::is_same<R, float>::value && d.n_triangles == 0 && d.n_boxes == 0 && d.n_spheres <= (size_t)kFlatMaxSpheres) {
     std::vector<DFlatRec> recs;
@@ -387,7 +251,7 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
   sc.spheres = push(pool, sph, ok); sc.planes = push(pool, pls, ok); sc.boxes = push(pool, boxes, ok);
   if constexpr (!std::is_same<R, double>::value) sc.tris = push(pool, tris, ok);
   sc.points = push(pool, pts, ok); sc.quads = push(pool, quads, ok); sc.disks = push(pool, disks, ok); sc.mats = push(pool, mats, ok);
-  sc.nodes = push(pool, nodes, ok);
+  if constexpr (std::is_same<R, double>::value) sc.nodes = push(pool, nodes, ok);
   sc.emissive = push(pool, emissive, ok);
   sc.images = d_images; sc.prims = d_prims;
   sc.n_spheres = (int)d.n_spheres; sc.n_planes = (int)d.n_planes; sc.n_tris = (int)d.n_triangles; sc.n_boxes = (int)d.n_boxes;
@@ -444,6 +308,7 @@ void HostBvh::build(const rtx_scene_desc& d) {
 void HostScene::release() {
   for (DeviceBuffer& b : pool) b.release();
   pool.clear();
+  wide.release();
   memset(&dev_f, 0, sizeof dev_f); memset(&dev_d, 0, sizeof dev_d); memset(&dev_ref, 0, sizeof dev_ref);
   h_spheres.clear(); h_materials.clear();
   n_nodes = n_prims = 0;
@@ -523,6 +388,37 @@ int HostScene::upload(const rtx_scene_desc& d, std::string& err) {
   fill_scene(dev_f, pool, d, bvh, emissive, d_images, d_prims, d_env, marginal, conditional, env_total, ok);
   lap("single-precision scene");
   dev_ref.nodes = d_nodes_ref; dev_ref.prims = d_prims; dev_ref.n_nodes = n_nodes; dev_ref.n_prims = n_prims;
+  if (ok && bvh.prims.size() > (size_t)kLinearMaxPrims) {
+    // What the GPU-built tree takes from the reference-order tree: every primitive's position in the reference's leaf order (ties
+    // in t go to the later one), and which primitives the reference can never hit (its slab test rejects a box that is flat along
+    // an axis, ref: engine/bvh.hpp:43, so the primitives of such a leaf are unreachable there).
+    const size_t np = bvh.prims.size(), ns = d.n_spheres, nt = d.n_triangles;
+    auto number = [&](const DPrimRef& p) -> size_t { return p.type == PRIM_SPHERE ? (size_t)p.index : p.type == PRIM_TRIANGLE ? ns + (size_t)p.index : ns + nt + (size_t)p.index; };
+    Staging<int32_t> rank(np);
+    parallel_for(np, [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) rank[number(bvh.prims[i])] = (int32_t)i; });
+    std::vector<uint8_t> dead;
+    std::mutex mu;
+    parallel_for(bvh.nodes.size(), [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        const DNodeRef& n = bvh.nodes[i];
+        if (n.count <= 0 || (n.lo[0] != n.hi[0] && n.lo[1] != n.hi[1] && n.lo[2] != n.hi[2])) continue;
+        std::lock_guard<std::mutex> g(mu);
+        if (dead.empty()) dead.assign(np, 0);
+        for (int k = 0; k < n.count; ++k) dead[number(bvh.prims[(size_t)n.first + k])] = 1;
+      }
+    });
+    dev_f.rank = push(pool, rank, ok);
+    const uint8_t* d_dead = dead.empty() ? nullptr : push(pool, dead, ok);
+    lap("ranks and unreachable primitives");
+    if (ok) {
+      std::string berr;
+      const int rc = build_wide_tree(dev_f, d_dead, wide, berr);
+      if (rc != RTX_OK) { release(); err = berr; return rc; }
+      dev_f.nodes8 = (const DNode8*)wide.nodes.ptr; dev_f.leaves3 = (const DLeaf3*)wide.leaves.ptr;
+      dev_f.n_nodes8 = wide.n_nodes; dev_f.n_leaves3 = wide.n_leaves; dev_f.walk_levels = wide.levels;
+    }
+    lap("eight-wide tree (GPU)");
+  }
   h_spheres.assign(d.spheres, d.spheres + d.n_spheres);
   h_materials.assign(d.materials, d.materials + d.n_materials);
   if (!ok) { release(); err = "device allocation or copy failed"; return RTX_ERR_OUT_OF_MEMORY; }

@@ -41,13 +41,25 @@ struct HostBvh {
   void build(const rtx_scene_desc& d);
 };
 
+// The eight-wide tree of the single-precision kernels, built on the GPU (bvh_build.hip).
+struct WideTree {
+  DeviceBuffer nodes, leaves;   // DNode8 / DLeaf3 records
+  int n_nodes = 0, n_leaves = 0, levels = 0;
+  double seconds = 0.0;         // device + host time of the build
+  void release() { nodes.release(); leaves.release(); n_nodes = n_leaves = levels = 0; }
+};
+// `sc`: the single-precision scene with its primitive tables already on the device; `d_dead`: optional device array, one byte per
+// bounded primitive (numbered spheres, triangles, boxes), non-zero = the reference can never hit it (built in as unhittable).
+int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& out, std::string& err);
+
 struct HostScene {
   DScene<float> dev_f;
   DScene<double> dev_d;
   DSceneRef dev_ref;
   int n_nodes = 0, n_prims = 0;
   double build_seconds = 0.0;
-  std::vector<DeviceBuffer> pool;   // owns every device allocation of the scene
+  WideTree wide;                    // walked by the single-precision kernels when the scene has more than kLinearMaxPrims bounded primitives
+  std::vector<DeviceBuffer> pool;   // owns every other device allocation of the scene
   std::vector<rtx_sphere> h_spheres;   // host copies the PathPhoton photon pass is planned from
   std::vector<rtx_material> h_materials;
   int upload(const rtx_scene_desc& d, std::string& err);
@@ -87,8 +99,13 @@ int launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, co
 void launch_film_reduce(const float* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream);
 void launch_film_reduce(const double* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream);
 void launch_postprocess(const float* film, unsigned char* out, int width, int height, int mapper, double exposure, hipStream_t stream);
-int launch_trace_fast(const DScene<float>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream);
-int launch_trace_fast(const DScene<double>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream);
+int launch_trace_fast(const DScene<float>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream, int n_cus = 256);
+int launch_trace_fast(const DScene<double>& sc, const double* rays8, unsigned long long n, DHitOut* out, int mode, size_t lds_bytes, hipStream_t stream, int n_cus = 256);
+// Grid of the production closest-hit kernel for a batch of n rays: grid-stride over the batch, a few workgroups per CU.
+inline unsigned trace_fast_grid(unsigned long long n, int n_cus) {
+  const unsigned long long want = (n + kBlock - 1) / kBlock, cap = (unsigned long long)n_cus * 8ull;
+  return (unsigned)(want < cap ? want : cap);
+}
 void launch_trace_ref(const DScene<double>& sc, const DSceneRef& ref, const double* rays8, unsigned long long n, DHitOut* out, hipStream_t stream);
 void launch_selftest(float* out, int n, hipStream_t stream);
 

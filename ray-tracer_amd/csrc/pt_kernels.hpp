@@ -9,12 +9,15 @@ namespace rtx {
 // Dynamic LDS of a workgroup: [material table (when staged)] [traversal stacks, [level][lane]].
 extern __shared__ int lds_dyn[];
 
-RTX_DEV LaneStack lane_stack(int first_int, int limit = kStackDepth) {
+// The first `limit` levels of a lane's traversal stack live in LDS; deeper ones in the scene's per-launch spill buffer (present
+// whenever the tree can need them: DScene::walk_spill).
+template <class R> RTX_DEV LaneStack lane_stack(const DScene<R>& sc, int first_int, int limit = kStackDepth) {
   LaneStack st;
   st.base = lds_dyn + first_int + threadIdx.x;
   st.stride = blockDim.x;
   st.limit = limit;
-  st.spill = nullptr; st.spill_stride = 0;
+  st.spill = sc.walk_spill ? sc.walk_spill + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) : nullptr;
+  st.spill_stride = sc.walk_spill_stride;
   return st;
 }
 
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? (INTEG == INTEG_PATHPH
   const uint32_t n_items = npix * (uint32_t)P.n_chunks;
   const uint32_t stride = gridDim.x * blockDim.x;
   uint32_t next = blockIdx.x * blockDim.x + threadIdx.x;
-  LaneStack st = lane_stack(stack_first_int);
+  LaneStack st = lane_stack(sc, stack_first_int);
 
   // Statistics: every trip adds the number of active lanes to wave-uniform counters.  A lane
   // that leaves the loop stops adding, so the lane that stays longest holds the wave's totals:
@@ -217,12 +220,11 @@ __global__ void film_reduce_kernel(const R* __restrict__ partial, float* __restr
 // Closest hit of a ray batch through the structure the integrator walks.
 template <class R, int MODE>
 __global__ __launch_bounds__(kBlock) void trace_fast_kernel(DScene<R> sc, const double* __restrict__ rays8, unsigned long long n, DHitOut* __restrict__ out) {
-  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
   const double* q = rays8 + i * 8ull;
   Ray<R> r = {{R(q[0]), R(q[1]), R(q[2])}, {R(q[3]), R(q[4]), R(q[5])}};
   Hit<R> h;
-  bool ok = trace_closest<R, MODE>(sc, r, R(q[6]), R(q[7]), h, lane_stack(0));
+  bool ok = trace_closest<R, MODE>(sc, r, R(q[6]), R(q[7]), h, lane_stack(sc, 0));
   DHitOut o;
   o.hit = ok; o.prim_type = ok ? h.type : -1; o.prim_index = ok ? h.idx : -1;
   o.material_id = ok ? h.mat : 0; o.front_face = ok ? h.front : 0; o.pad = 0;
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(kBlock) void trace_fast_kernel(DScene<R> sc, const 
   o.normal[0] = ok ? (double)h.n.x : 0.0; o.normal[1] = ok ? (double)h.n.y : 0.0; o.normal[2] = ok ? (double)h.n.z : 0.0;
   o.u = ok ? (double)h.u : 0.0; o.v = ok ? (double)h.v : 0.0;
   out[i] = o;
+  }
 }
 
 }  // namespace rtx

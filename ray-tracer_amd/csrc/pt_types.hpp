@@ -33,36 +33,42 @@ struct DPrimRef { int32_t type, index; };
 // left child of node i is i+1.  count > 0: leaf over prims[a .. a+count); else a = right child.
 template <class R> struct DNode2 { R lo[3], hi[3]; int32_t a, count; };
 
-// Single-precision traversal layout.  One 64-byte record per INNER node holds the boxes of both
-// children (so a traversal step is one 64-byte fetch and the box of a popped node is never
-// re-read); a child code >= 0 is another record, a negative code ~((first << 2) | count) is a
-// leaf over leaf_prims[first .. first+count).  Boxes are rounded outward, except flat ones.
-struct alignas(16) DNodePair { float lo_l[3], hi_l[3], lo_r[3], hi_r[3]; int32_t cl, cr, pad0, pad1; };
-// Four-wide form of the same tree for the queue-based traversal kernels, whose speed is set
-// by the number of dependent fetches per ray: every other level of the binary tree is folded
-// away, so a record (128 bytes, two cache lines) holds the boxes of up to four grandchildren,
-// component-wise.  child[k]: >= 0 another record, < 0 a leaf code as above, kWideEmpty = unused.
-struct alignas(16) DNodeWide { float lo_x[4], lo_y[4], lo_z[4], hi_x[4], hi_y[4], hi_z[4]; int32_t child[4]; int32_t pad[4]; };
-constexpr int32_t kWideEmpty = 0x7ffffffe;
-// The same record in 64 bytes (half a cache line per traversal step instead of a whole one): the four boxes as 8-bit
-// offsets from the record's own origin in units of 2^e per axis, rounded outward (Ylitie, Karras, Laine: "Efficient
-// Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017).  exps = biased float exponents of the three
-// units, one per byte; byte k of qlo[a] / qhi[a] belongs to child k.  A child that is flat along an axis, which the
-// strict slab test never enters, is stored as kWideEmpty.
-struct alignas(16) DNodeWideQ { float org[3]; uint32_t exps; uint32_t qlo[3], qhi[3]; int32_t child[4]; uint32_t pad[2]; };
-#ifndef RTX_WIDE_QUANT
-#define RTX_WIDE_QUANT 1
-#endif
-// Levels of a four-wide walk's stack kept in LDS; deeper levels (rare) spill to global memory.
+// Single-precision traversal layout: an eight-wide tree built on the GPU (bvh_build.hip) from the Morton order of the
+// primitives' centroids.  Its topology is its own (closest hits do not depend on it: boxes are conservative, and a tie in t
+// is resolved by the primitives' positions in the REFERENCE's leaf order, DScene::rank); only the reference-order tree above
+// decides which primitives can be hit at all (a primitive whose reference leaf box is flat along an axis is never reached
+// there and is built into this tree as unhittable).
+//
+// One node record is one 128-byte line: the boxes of up to eight children as 8-bit offsets from the node's own origin in
+// units of 2^e per axis, rounded outward (Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs Through
+// Compressed Wide BVHs", HPG 2017).  Children 0 .. n_inner-1 are the nodes inner_base + k, children n_inner .. n_child-1 the
+// leaf records leaf_base + (k - n_inner); unused slots hold an inverted box (255, 0) that no ray enters.
+struct alignas(128) DNode8 {
+  float org[3];
+  uint32_t exps;          // byte a (0..2): biased float exponent of axis a's unit; bits 24-27: n_inner; bits 28-31: n_child - 1
+  uint32_t qlo[3][2];     // byte (k & 3) of qlo[a][k >> 2]: child k's lower plane on axis a
+  uint32_t qhi[3][2];
+  int32_t inner_base, leaf_base;
+  uint32_t pad[14];
+};
+// One leaf record is one 128-byte line: up to three triangles with their vertices in place.  id = the primitive's number in
+// the reference's primitive list (spheres, then triangles, then boxes: engine/scene.hpp:496-533), -1 for an empty slot.  A
+// slot that holds a sphere or a box (bit k of `other`) or nothing has NaN vertices, which fail the triangle test.
+struct alignas(128) DLeaf3 {
+  float v[3][9];
+  int32_t id[3];
+  int32_t count;
+  uint32_t other;
+};
+constexpr int kLeafMaxPrims = 3;
+constexpr int kWalkDone = 0x7fffffff;
+// Levels of a walk's stack kept in LDS by the queue-based traversal kernels; deeper levels spill to global memory.
 constexpr int kWalkLdsLevels = 12;
 // Shading record of one primitive of a flat scene, in the order the flat intersection tests them (spheres in the
 // reference's leaf order, planes, quad lights, disk lights): what the winner's normal and material need, fetched
 // once per hit instead of being carried through every test.  sphere: (a,b,c) = centre, w = 1 / radius; others:
 // (a,b,c) = outward normal, w = 0.
 struct alignas(16) DFlatRec { float a, b, c, w; int32_t mat, type, idx, pad; };
-// Leaf-ordered primitive records (48 bytes, three 16-byte fetches): a triangle's vertices in
-// place, or (type != PRIM_TRIANGLE) a reference to a sphere / box tested through its own table.
-struct alignas(16) DLeafPrim { float v0[3]; int32_t mat; float v1[3]; int32_t index; float v2[3]; int32_t type; };
 
 template <class R> struct DEnv {
   const float* texel;        // RGB, row 0 = top
@@ -78,12 +84,14 @@ template <class R> struct DScene {
   const DPoint<R>* points; const DQuad<R>* quads; const DDisk<R>* disks; const DMaterial<R>* mats;
   const DImage* images; const int32_t* emissive;   // indices of emissive spheres, ascending
   const DNode2<R>* nodes; const DPrimRef* prims;    // production BVH + primitive order (reference leaf order)
-  const DNodePair* pairs; const DLeafPrim* leaf_prims; // single-precision traversal layout (NULL in the double scene)
-  const DNodeWide* wide;                               // one of the two four-wide forms is built (RTX_WIDE_QUANT)
-  const DNodeWideQ* wideq;
+  const DNode8* nodes8; const DLeaf3* leaves3;         // single-precision traversal layout (NULL in the double scene and for scenes tested linearly)
+  const int32_t* rank;                                 // position of every bounded primitive (numbered as DLeaf3::id) in the reference's leaf order
   const DFlatRec* flat;                                // flat scenes only (single precision)
+  // Overflow levels of the eight-wide walk's per-lane stack, [level][lane of the grid], set per launch by the host when the tree
+  // is deeper than the LDS part holds: a walk parks at most 7 siblings per level, so 7 * levels + 1 entries always suffice.
+  int32_t* walk_spill; int32_t walk_spill_stride;
   int32_t n_spheres, n_planes, n_tris, n_boxes, n_points, n_quads, n_disks, n_mats, n_images, n_emissive;
-  int32_t n_nodes, n_prims, n_pairs, n_wide;
+  int32_t n_nodes, n_prims, n_nodes8, n_leaves3, walk_levels;
   int32_t n_nmaps;                                     // materials with a normal map (picks the kernel instances that apply them)
   DEnv<R> env;
 };

@@ -205,19 +205,18 @@ __device__ unsigned long long g_walk_stats[8];   // diagnostic build only
 #endif
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int q, int stack_levels, int* spill, DCounters* counters) {
+__global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int q, int stack_levels, DCounters* counters) {
   const uint32_t n = ctl->n_q[q];
   uint32_t n_nodes = 0, n_prims = 0;   // node records and leaf primitives this lane tested
   bool more = true;   // wave-uniform: the queue may still have entries
-  LaneStack st = lane_stack(0, stack_levels);
-  st.spill = spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x; st.spill_stride = (int)(gridDim.x * blockDim.x);
+  LaneStack st = lane_stack(sc, 0, stack_levels);
   const bool tree = MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims;
   uint32_t slot = 0;
   Ray<float> ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
   Cand<float> c;
-  PairWalk w;
+  Walk8 w;
   cand_init(c, 1e9f);
-  w.node = kWalkDone; w.sp = 0; w.rank = -1; w.inv = {0.f, 0.f, 0.f};
+  w.node = kWalkDone; w.sp = 0; w.best_p = -1; w.inv = {0.f, 0.f, 0.f};
   int state = 0;   // 0 no ray, 1 walking, 2 walk finished, result not yet stored
   for (;;) {
     // Refill in batches: finished lanes wait until enough of the wave is idle, then store their
@@ -244,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A
         ray.o = {A.ray[0][slot], A.ray[1][slot], A.ray[2][slot]};
         ray.d = {A.ray[3][slot], A.ray[4][slot], A.ray[5][slot]};
         cand_init(c, 1e9f);
-        if (tree) pair_walk_begin(w, ray);
+        if (tree) walk8_begin(w, ray);
         state = 1;
       }
       if (__ballot(state == 1) == 0ull) break;
@@ -254,18 +253,18 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A
     } else if (!tree) {
       if (state == 1) { walk_bounded<float, false>(sc, ray, 0.001f, c, st); state = 2; }
     } else {
-      const bool inner = state == 1 && pair_walk_at_inner(w);
+      const bool inner = state == 1 && walk8_at_inner(w);
 #ifdef RTX_WALK_STATS
       { const unsigned long long mi = __ballot(inner); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_walk_stats[0], 1ull); if (mi) { atomicAdd(&g_walk_stats[1], 1ull); atomicAdd(&g_walk_stats[2], (unsigned long long)__popcll(mi)); } } }
 #endif
-      if (inner) { pair_walk_inner(sc, ray, 0.001f, c, w, st); ++n_nodes; }
+      if (inner) { walk8_inner<true>(sc, ray, 0.001f, c.t, w, st); ++n_nodes; }
       // leaves wait until a batch of lanes has one, or until no lane has an inner node left
-      const bool leaf = state == 1 && pair_walk_at_leaf(w);
-      if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && pair_walk_at_inner(w)) == 0ull) {
+      const bool leaf = state == 1 && walk8_at_leaf(w);
+      if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
 #ifdef RTX_WALK_STATS
         { const unsigned long long ml = __ballot(leaf); if ((threadIdx.x & 63) == 0 && ml) { atomicAdd(&g_walk_stats[3], 1ull); atomicAdd(&g_walk_stats[4], (unsigned long long)__popcll(ml)); } }
 #endif
-        if (leaf) { pair_walk_leaf<false>(sc, ray, 0.001f, c, w, st); ++n_prims; }
+        if (leaf) { walk8_leaf<false>(sc, ray, 0.001f, c, w, st); ++n_prims; }
       }
       if (state == 1 && w.node == kWalkDone) state = 2;
     }
@@ -344,19 +343,18 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DRend
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int stack_levels, int* spill) {
+__global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int stack_levels) {
   const uint32_t n = ctl->n_shadow;
   bool more = true;   // wave-uniform: the queue may still have entries
-  LaneStack st = lane_stack(0, stack_levels);
-  st.spill = spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x; st.spill_stride = (int)(gridDim.x * blockDim.x);
+  LaneStack st = lane_stack(sc, 0, stack_levels);
   const bool tree = MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims;
   uint32_t i = 0;
   float t_max = 0.f;
   Ray<float> sr = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
   Cand<float> c;
-  PairWalk w;
+  Walk8 w;
   cand_init(c, 1e9f);
-  w.node = kWalkDone; w.sp = 0; w.rank = -1; w.inv = {0.f, 0.f, 0.f};
+  w.node = kWalkDone; w.sp = 0; w.best_p = -1; w.inv = {0.f, 0.f, 0.f};
   int state = 0;   // 0 no ray, 1 walking, 2 finished (occluded), 3 finished (visible)
   for (;;) {
     if (__popcll(__ballot(state == 1)) < kRefillBelow) {
@@ -374,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays 
           sr.d = {A.sh[3][i], A.sh[4][i], A.sh[5][i]};
           t_max = A.sh[6][i];
           cand_init(c, t_max);
-          if (tree) pair_walk_begin(w, sr);
+          if (tree) walk8_begin(w, sr);
           state = 1;
         }
       }
@@ -385,28 +383,31 @@ __global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays 
     } else if (!tree) {
       if (state == 1) state = occluded(sc, sr, 0.001f, t_max, st) ? 2 : 3;
     } else {
-      const bool inner = state == 1 && pair_walk_at_inner(w);
-      if (inner) pair_walk_inner(sc, sr, 0.001f, c, w, st);
-      const bool leaf = state == 1 && pair_walk_at_leaf(w);
-      if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && pair_walk_at_inner(w)) == 0ull) {
-        if (leaf) pair_walk_leaf<true>(sc, sr, 0.001f, c, w, st);
+      const bool inner = state == 1 && walk8_at_inner(w);
+      if (inner) walk8_inner<false>(sc, sr, 0.001f, c.t, w, st);
+      const bool leaf = state == 1 && walk8_at_leaf(w);
+      if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
+        if (leaf) walk8_leaf<true>(sc, sr, 0.001f, c, w, st);
       }
       if (state == 1 && w.node == kWalkDone) state = (c.type >= 0 || occluded_unbounded(sc, sr, 0.001f, t_max)) ? 2 : 3;
     }
   }
 }
 
-template <int MODE> void launch_iteration_kernels(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, const WfArrays& A, WfControl* ctl,
+template <int MODE> void launch_iteration_kernels(const DScene<float>& sc_in, const DCamera<float>& cam, const DRenderParams& P, const WfArrays& A, WfControl* ctl,
                                                   float* partial, DCounters* counters, bool lds_mats, size_t mat_lds, int stack_levels, unsigned grid,
                                                   unsigned resident_blocks, int step /*0 first generate, 1 shade, 2 connect, 3 generate*/, int qa, int qb,
                                                   hipStream_t stream, uint32_t& launches, int* spill, WavefrontPool& pool) {
+  // the persistent traversal kernels take the overflow levels of their stacks through the scene record, [level][lane of the grid]
+  DScene<float> sc = sc_in;
+  sc.walk_spill = spill; sc.walk_spill_stride = (int32_t)((grid < resident_blocks ? grid : resident_blocks) * (unsigned)kBlock);
   const dim3 g((grid + (kStreamBlock / kBlock) - 1) / (kStreamBlock / kBlock)), bs(kStreamBlock), b(kBlock);   // `grid` counts kBlock-sized groups
   const dim3 gw(grid < resident_blocks ? grid : resident_blocks);   // persistent traversal kernels
   const size_t walk_lds = MODE == MODE_FLAT ? 0 : (size_t)stack_levels * kBlock * sizeof(int);
   if (step == 0 || step == 3) {
     hipLaunchKernelGGL(wf_generate, g, bs, 0, stream, cam, P, A, ctl, step == 0 ? 1 : 0, qa, qb, partial, counters);
     pool.mark(stream);
-    hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, qb, stack_levels, spill, counters);
+    hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, qb, stack_levels, counters);
     pool.mark(stream);
     ++launches;
   } else if (step == 1) {
@@ -416,7 +417,7 @@ template <int MODE> void launch_iteration_kernels(const DScene<float>& sc, const
     } else if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, P, A, ctl, qa, counters);
     else hipLaunchKernelGGL((wf_shade<MODE, false>), g, bs, 0, stream, sc, P, A, ctl, qa, counters);
   } else
-    hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, stack_levels, spill);
+    hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, stack_levels);
 }
 
 // Blocks of the traversal kernels one CU keeps resident (the smaller of the two kernels' figures).
@@ -470,9 +471,13 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   const int per_cu = mode == MODE_FLAT ? walk_blocks_per_cu<MODE_FLAT>(stack_levels) : mode == MODE_TREE ? walk_blocks_per_cu<MODE_TREE>(stack_levels)
                                                                                                        : walk_blocks_per_cu<MODE_TREE_UV>(stack_levels);
   const unsigned resident = (unsigned)n_cus * (unsigned)per_cu;
-  // overflow levels of the traversal stacks: the LDS part holds kWalkLdsLevels, the walk can park three children per wide level
-  if (!pool.spill.ensure((size_t)resident * kBlock * (size_t)kStackDepth * sizeof(int))) { err = "pool allocation"; return RTX_ERR_OUT_OF_MEMORY; }
-  int* spill = (int*)pool.spill.ptr;
+  // overflow levels of the traversal stacks: the LDS part holds stack_levels entries, a walk parks at most seven siblings per level
+  const int stack_need = 7 * sc.walk_levels + 1;
+  int* spill = nullptr;
+  if (sc.n_nodes8 > 0 && stack_need > stack_levels) {
+    if (!pool.spill.ensure((size_t)resident * kBlock * (size_t)(stack_need - stack_levels) * sizeof(int))) { err = "pool allocation"; return RTX_ERR_OUT_OF_MEMORY; }
+    spill = (int*)pool.spill.ptr;
+  }
 
   auto run = [&](int step, int qa, int qb, unsigned grid) {
     if (mode == MODE_FLAT) launch_iteration_kernels<MODE_FLAT>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill, pool);
