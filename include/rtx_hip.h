@@ -199,6 +199,19 @@ int rtx_render(rtx_ctx* ctx, const rtx_settings* settings, float* out_rgb, rtx_s
  * kernels have finished (stats need the device counters). */
 int rtx_render_device(rtx_ctx* ctx, const rtx_settings* settings, void* d_out_rgb, void* hip_stream, rtx_stats* stats);
 
+/* rtx_render_device for callers that cannot allocate device memory while they run: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  It allocates nothing (no hipMalloc /
+ * hipFree, no allocating library routine): the chunk sums and counters of the render live in a 64 MiB array that is part of the
+ * library's code object on every GPU (held until the process ends), and the kernels are the ones rtx_render_device launches,
+ * so the film is the same bit for bit.  Limits, each refused with a message: single precision, RTX_MODE_PATHTRACE or
+ * RTX_MODE_WHITTED, the fused pipeline (RTX_PIPELINE_AUTO must resolve to it: scenes of at most 12 bounded primitives, or
+ * pipeline = RTX_PIPELINE_FUSED with a tree of at most 6 levels), use_mnee = 0, and
+ * rows_of_shard * width * chunks * 12 bytes <= 64 MiB - 256, chunks = min(samples_per_pixel, 16) (e.g. 640x360 at any sample
+ * count, 1920x1080 at 2 samples per pixel).  With stats = NULL the call only enqueues work on `hip_stream` (NULL = the context's
+ * stream) and returns; with stats it also waits for the kernels and fills them.  Every call on one GPU uses that GPU's one
+ * array: calls that overlap in time on the same GPU (other contexts, other streams) race; calls on one stream do not. */
+int rtx_render_device_noalloc(rtx_ctx* ctx, const rtx_settings* settings, void* d_out_rgb, void* hip_stream, rtx_stats* stats);
+
 /* Replaces Image::apply_tone_mapping followed by the quantisation of Image::write_png / write_ppm
  * (engine/renderer.cpp:186-198 with the operators of :102-184, then :232-258; called from main.cpp:399-431 on the
  * GPU branch and renderer.cpp after the CPU render): per channel  c = film * exposure;  tone map;  clamp to [0,1];

@@ -123,6 +123,7 @@ EXPORTS = {
     "rtx_set_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
     "rtx_render": (C.c_int, [C.c_void_p, C.POINTER(Settings), C.POINTER(C.c_float), C.POINTER(Stats)]),
     "rtx_render_device": (C.c_int, [C.c_void_p, C.POINTER(Settings), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
+    "rtx_render_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(Settings), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "rtx_postprocess": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_uint8)]),
     "rtx_postprocess_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]),
     "rtx_trace_closest": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(Hit)]),

@@ -16,6 +16,14 @@ void launch_selftest(float* out, int n, hipStream_t stream) {
   hipLaunchKernelGGL(selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n);
 }
 
+__global__ void zero_words_kernel(uint32_t* p, unsigned n) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+void launch_zero_words(uint32_t* p, unsigned n, hipStream_t stream) {
+  if (n) hipLaunchKernelGGL(zero_words_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n);
+}
+
 void launch_photon_trace(const DScene<float>& sc, const DRenderParams& P, const DPhotonLight* lights, int n_lights, const int32_t* targets, int n_targets,
                          uint32_t n_photons, float* out, DCounters* counters, size_t lds_bytes, hipStream_t stream) {
   const unsigned grid = (n_photons + kBlock - 1) / kBlock;

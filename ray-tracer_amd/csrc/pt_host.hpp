@@ -108,6 +108,7 @@ inline unsigned trace_fast_grid(unsigned long long n, int n_cus) {
 }
 void launch_trace_ref(const DScene<double>& sc, const DSceneRef& ref, const double* rays8, unsigned long long n, DHitOut* out, hipStream_t stream);
 void launch_selftest(float* out, int n, hipStream_t stream);
+void launch_zero_words(uint32_t* p, unsigned n, hipStream_t stream);   // p[0 .. n) = 0 by a kernel (no memset node)
 
 // Wavefront pipeline (wavefront.hip): queue storage + the per-iteration launch loop.
 struct WavefrontPool {

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -51,8 +52,38 @@ template <class F> int guarded(F&& f) {
 
 using namespace rtx;
 
+// ------------------------------------------------------------------------------------------
+// Scratch memory of rtx_render_device_noalloc: the chunk sums and counters of a render live in this array of the code object
+// instead of buffers the library allocates.  Every GPU the library is loaded on holds its own copy at its own address; the
+// array's name is only a host-side handle, so the device address is looked up once per device (scratch_pointer) and that
+// pointer, never the name, is what kernels and fills receive.
+// ------------------------------------------------------------------------------------------
+constexpr size_t kScratchBytes = 64ull << 20;
+constexpr size_t kScratchHeader = 256;   // the counters, ahead of the chunk sums
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// Device address of `scratch` on `device`, which must be the current device.  nullptr + error message on failure.
+unsigned char* scratch_pointer(int device) {
+  if (device < 0 || device >= kMaxDevices) { fail(RTX_ERR_INVALID_ARGUMENT, "device %d: the scratch table holds %d devices", device, kMaxDevices); return nullptr; }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) { fail(RTX_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e)); return nullptr; }
+    g_scratch_ptr[device] = (unsigned char*)p;
+  }
+  return g_scratch_ptr[device];
+}
+}  // namespace
+
 struct rtx_ctx {
   int device = 0;
+  unsigned char* scratch_dev = nullptr;   // this device's copy of `scratch`
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;
   int n_cus = 256;
@@ -226,8 +257,11 @@ static int create_impl(rtx_ctx** out_ctx, int device_id) {
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return fail(RTX_ERR_NO_DEVICE, "no HIP device visible");
   if (device_id < 0 || device_id >= n_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device_id, n_dev);
   HIP_TRY(hipSetDevice(device_id));
+  unsigned char* scratch_dev = scratch_pointer(device_id);   // once per device, with that device current
+  if (!scratch_dev) return RTX_ERR_HIP;
   rtx_ctx* c = new rtx_ctx();
   c->device = device_id;
+  c->scratch_dev = scratch_dev;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount;
   if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->evm) != hipSuccess) {
@@ -298,7 +332,9 @@ int rtx_get_bvh_info(rtx_ctx* c, rtx_bvh_info* out) {
 }
 
 
-static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, rtx_stats* stats) {
+// `no_alloc`: the render may not allocate (rtx_render_device_noalloc): its chunk sums and counters go to the device's scratch
+// array, and whatever would need another buffer is refused.
+static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, rtx_stats* stats, bool no_alloc = false) {
   if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
   if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "render before upload_scene");
   if (!c->has_camera) return fail(RTX_ERR_NOT_READY, "render before set_camera");
@@ -361,12 +397,26 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   if (pipeline == RTX_PIPELINE_WAVEFRONT && f64) return fail(RTX_ERR_UNSUPPORTED, "the wavefront pipeline is single precision only");
 
   float* d_film = (float*)dev_out;
-  if (!d_film) {
-    if (!c->film.ensure(npix * 3 * sizeof(float))) return fail(RTX_ERR_OUT_OF_MEMORY, "film buffer");
-    d_film = (float*)c->film.ptr;
+  void* partial_ptr = nullptr;
+  DCounters* counters_ptr = nullptr;
+  if (no_alloc) {
+    if (f64 || mnee || bdpt || photon) return fail(RTX_ERR_UNSUPPORTED, "the no-allocation render runs single-precision PathTrace and Whitted only");
+    if (pipeline != RTX_PIPELINE_FUSED) return fail(RTX_ERR_UNSUPPORTED, "the no-allocation render runs the fused pipeline only (this scene and these settings select the queue-based one)");
+    if (c->scene.wide.n_nodes > 0 && 7 * c->scene.wide.levels + 1 > kStackDepth)
+      return fail(RTX_ERR_UNSUPPORTED, "the no-allocation render holds traversal stacks in LDS only: this scene's tree has %d levels (at most %d)", c->scene.wide.levels, (kStackDepth - 1) / 7);
+    static_assert(sizeof(DCounters) <= kScratchHeader, "counters must fit the scratch header");
+    counters_ptr = (DCounters*)c->scratch_dev;
+    partial_ptr = c->scratch_dev + kScratchHeader;
+    launch_zero_words((uint32_t*)counters_ptr, (unsigned)(sizeof(DCounters) / 4), stream);   // a fill kernel, not a memset node: callers may capture this call
+  } else {
+    if (!d_film) {
+      if (!c->film.ensure(npix * 3 * sizeof(float))) return fail(RTX_ERR_OUT_OF_MEMORY, "film buffer");
+      d_film = (float*)c->film.ptr;
+    }
+    if (!c->counters.ensure(sizeof(DCounters))) return fail(RTX_ERR_OUT_OF_MEMORY, "counters");
+    counters_ptr = (DCounters*)c->counters.ptr;
+    HIP_TRY(hipMemsetAsync(counters_ptr, 0, sizeof(DCounters), stream));
   }
-  if (!c->counters.ensure(sizeof(DCounters))) return fail(RTX_ERR_OUT_OF_MEMORY, "counters");
-  HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DCounters), stream));
 
   const bool needs_stack = c->scene.n_prims > kLinearMaxPrims;
   if (!photon) HIP_TRY(hipEventRecord(c->ev0, stream));   // PathPhoton records it behind its photon pass
@@ -374,7 +424,15 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     const size_t elem = f64 ? sizeof(double) : sizeof(float);
     const unsigned long long items = npix * (unsigned long long)P.n_chunks;
     if (items >= 0x7fffffffull) return fail(RTX_ERR_INVALID_ARGUMENT, "film too large for one launch (%llu work items)", items);
-    if (!c->partial.ensure((size_t)items * 3 * elem)) return fail(RTX_ERR_OUT_OF_MEMORY, "chunk-sum buffer (%llu bytes)", (unsigned long long)(items * 3 * elem));
+    if (no_alloc) {
+      if ((unsigned long long)items * 3ull * elem > kScratchBytes - kScratchHeader)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "the no-allocation render holds %llu bytes of chunk sums: %d x %d pixels in %d sample chunks need %llu (at most %llu pixel-chunks)",
+                    (unsigned long long)(kScratchBytes - kScratchHeader), P.width, P.rows, P.n_chunks, (unsigned long long)items * 3ull * elem,
+                    (unsigned long long)((kScratchBytes - kScratchHeader) / (3 * elem)));
+    } else {
+      if (!c->partial.ensure((size_t)items * 3 * elem)) return fail(RTX_ERR_OUT_OF_MEMORY, "chunk-sum buffer (%llu bytes)", (unsigned long long)(items * 3 * elem));
+      partial_ptr = c->partial.ptr;
+    }
     FusedLaunch L;
     L.mode = whitted ? MODE_TREE_UV : c->scene.fused_mode(f64);
     if (photon && L.mode != MODE_FLAT) L.mode = MODE_TREE_UV;   // PathPhoton: the flat instance (single precision, small untextured scenes) or the general one
@@ -410,33 +468,34 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
       if ((unsigned long long)L.grid * kBlock > max_lanes) L.grid = (int)(max_lanes / kBlock);
       if (!c->bdpt_store.ensure((size_t)((unsigned long long)L.grid * kBlock * per_lane))) return fail(RTX_ERR_OUT_OF_MEMORY, "BDPT light-vertex store (%llu bytes)", (unsigned long long)L.grid * kBlock * per_lane);
       if (!f64 && !set_walk_spill(c, scf, (size_t)L.grid * kBlock, kStackDepth)) return fail(RTX_ERR_OUT_OF_MEMORY, "traversal stacks");
-      if (f64) lrc = launch_render_bdpt(c->scene.dev_d, c->cam_d, P, (double*)c->partial.ptr, (DCounters*)c->counters.ptr, L, (double*)c->bdpt_store.ptr, cap, stream);
-      else lrc = launch_render_bdpt(scf, c->cam_f, P, (float*)c->partial.ptr, (DCounters*)c->counters.ptr, L, (float*)c->bdpt_store.ptr, cap, stream);
+      if (f64) lrc = launch_render_bdpt(c->scene.dev_d, c->cam_d, P, (double*)partial_ptr, counters_ptr, L, (double*)c->bdpt_store.ptr, cap, stream);
+      else lrc = launch_render_bdpt(scf, c->cam_f, P, (float*)partial_ptr, counters_ptr, L, (float*)c->bdpt_store.ptr, cap, stream);
       HIP_TRY(hipEventRecord(c->evm, stream));
-      if (f64) launch_film_reduce((const double*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
-      else launch_film_reduce((const float*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
+      if (f64) launch_film_reduce((const double*)partial_ptr, d_film, npix, P.n_chunks, P.spp, stream);
+      else launch_film_reduce((const float*)partial_ptr, d_film, npix, P.n_chunks, P.spp, stream);
     } else if (f64) {
-      lrc = launch_render_fused(c->scene.dev_d, c->cam_d, P, (double*)c->partial.ptr, (DCounters*)c->counters.ptr, L, stream);
+      lrc = launch_render_fused(c->scene.dev_d, c->cam_d, P, (double*)partial_ptr, counters_ptr, L, stream);
       HIP_TRY(hipEventRecord(c->evm, stream));
-      launch_film_reduce((const double*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
+      launch_film_reduce((const double*)partial_ptr, d_film, npix, P.n_chunks, P.spp, stream);
     } else {
       if (!set_walk_spill(c, scf, (size_t)L.grid * kBlock, kStackDepth)) return fail(RTX_ERR_OUT_OF_MEMORY, "traversal stacks");
-      lrc = launch_render_fused(scf, c->cam_f, P, (float*)c->partial.ptr, (DCounters*)c->counters.ptr, L, stream);
+      lrc = launch_render_fused(scf, c->cam_f, P, (float*)partial_ptr, counters_ptr, L, stream);
       HIP_TRY(hipEventRecord(c->evm, stream));
-      launch_film_reduce((const float*)c->partial.ptr, d_film, npix, P.n_chunks, P.spp, stream);
+      launch_film_reduce((const float*)partial_ptr, d_film, npix, P.n_chunks, P.spp, stream);
     }
     if (lrc != 0) return fail(RTX_ERR_UNSUPPORTED, "no kernel instance for mode %d", L.mode);
     st.kernel_launches = photon ? 3 : 2;
   } else {
     std::string err;
-    int rc = wavefront_render(c->wf, c->scene.dev_f, c->cam_f, P, d_film, (DCounters*)c->counters.ptr, c->n_cus, c->scene.fused_mode(false), needs_stack ? kWalkLdsLevels : 0, stream, st.kernel_launches, err);
+    int rc = wavefront_render(c->wf, c->scene.dev_f, c->cam_f, P, d_film, counters_ptr, c->n_cus, c->scene.fused_mode(false), needs_stack ? kWalkLdsLevels : 0, stream, st.kernel_launches, err);
     if (rc != RTX_OK) return fail(rc, "wavefront: %s", err.c_str());
     HIP_TRY(hipEventRecord(c->evm, stream));
   }
   HIP_TRY(hipEventRecord(c->ev1, stream));
   HIP_TRY(hipGetLastError());
+  if (no_alloc && !stats) return RTX_OK;   // enqueued only: the caller synchronises its stream
   DCounters hc;
-  HIP_TRY(hipMemcpyAsync(&hc, c->counters.ptr, sizeof hc, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(&hc, counters_ptr, sizeof hc, hipMemcpyDeviceToHost, stream));
   if (host_out) HIP_TRY(hipMemcpyAsync(host_out, d_film, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   float ms = 0.f;
@@ -457,6 +516,11 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
 int rtx_render(rtx_ctx* c, const rtx_settings* s, float* out_rgb, rtx_stats* stats) {
   if (!out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "out_rgb is NULL");
   return guarded([&] { return render_impl(c, s, out_rgb, nullptr, nullptr, stats); });
+}
+
+int rtx_render_device_noalloc(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* hip_stream, rtx_stats* stats) {
+  if (!d_out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "d_out_rgb is NULL");
+  return guarded([&] { return render_impl(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, stats, true); });
 }
 
 int rtx_render_device(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* hip_stream, rtx_stats* stats) {

@@ -86,6 +86,18 @@ class HipPathTracer:
         self.last_stats = stats
         return stats
 
+    def render_device_noalloc(self, device_ptr: int, stream: int = 0, want_stats: bool = True) -> abi.Stats | None:
+        """rtx_render_device_noalloc: the same render without any device allocation (small films, fused pipeline)."""
+        st = self._settings
+        if st is None:
+            raise abi.RtxError("render before set_settings")
+        stats = abi.Stats() if want_stats else None
+        abi.check(self._lib, self._lib.rtx_render_device_noalloc(self._ctx, C.byref(st), C.c_void_p(device_ptr), C.c_void_p(stream),
+                                                                  C.byref(stats) if want_stats else None), "rtx_render_device_noalloc")
+        if want_stats:
+            self.last_stats = stats
+        return stats
+
     def postprocess(self, film: np.ndarray, tone_mapper: int = TM_ACES, exposure: float = 1.0) -> np.ndarray:
         """Image::apply_tone_mapping + the quantisation of Image::write_png (engine/renderer.cpp:186-198,
         :232-258) on the GPU: uint8 [H, W, 3], row 0 = TOP, from a float film with row 0 = bottom."""
