@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, c
     while (e < 127 && ceil(ext / ldexp(1.0, e)) > 255.0) ++e;
     exps |= (uint32_t)(e + 127) << (8 * a);
     const double inv_unit = ldexp(1.0, -e);
-    int ql = 255, qh = 0;   // an unused slot or an empty child: inverted, entered by no ray
+    int ql = 0, qh = 0;   // an unused slot (never tested) or a child without a hittable primitive (a point: its leaf holds NaN vertices)
     if (!node_empty && clo[0] <= chi[0]) {
       ql = (int)floor(((double)clo[a] - (double)lo[a]) * inv_unit);
       qh = (int)ceil(((double)chi[a] - (double)lo[a]) * inv_unit);
@@ -294,7 +294,11 @@ int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& ou
                        lo4.as<float4>(), hi4.as<float4>(), nlo.as<float4>(), nhi.as<float4>(), (DNode8*)out.nodes.ptr, (DLeaf3*)out.leaves.ptr, sc.tris, ns, nt);
   }
   BUILD_TRY(hipGetLastError());
+  float4 root_lo, root_hi;
+  BUILD_TRY(hipMemcpyAsync(&root_lo, nlo.p, sizeof root_lo, hipMemcpyDeviceToHost, stream));
+  BUILD_TRY(hipMemcpyAsync(&root_hi, nhi.p, sizeof root_hi, hipMemcpyDeviceToHost, stream));
   BUILD_TRY(hipStreamSynchronize(stream));
+  out.lo[0] = root_lo.x; out.lo[1] = root_lo.y; out.lo[2] = root_lo.z; out.hi[0] = root_hi.x; out.hi[1] = root_hi.y; out.hi[2] = root_hi.z;
   out.n_nodes = n_nodes; out.n_leaves = n_leaves; out.levels = levels;
   out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return RTX_OK;

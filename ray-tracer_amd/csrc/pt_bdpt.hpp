@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(R) == 4 ? RTX_BDPT_MIN_WAVES : 1)) 
   const uint32_t n_items = npix * (uint32_t)P.n_chunks;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-  LaneStack st = lane_stack(sc, stack_first_int);
+  LaneStack st = lane_stack(stack_first_int);
   BdptStore<R> store = {light_store + lane, (size_t)stride, (size_t)store_cap};
   BdptTally tl = {0u, 0u, 0u};
   uint32_t n_samples = 0;

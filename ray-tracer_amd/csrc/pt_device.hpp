@@ -316,20 +316,17 @@ template <class R, bool WANT_UV> RTX_DEV void finalize_hit(const DScene<R>& sc, 
 // Per-lane traversal stack in LDS, laid out [level][lane] so a wave's accesses to one level
 // are one conflict-free row.
 struct LaneStack {
-  int* base; int stride; int limit;   // limit = levels the kernel's LDS allocation holds
-  int* spill; int spill_stride;       // optional overflow levels in global memory, [level][lane of the grid]
+  int* base; int stride;   // word i of this lane's stack is base[i * stride]
   RTX_DEV int& at(int level) const { return base[level * stride]; }
-  // push / pop with overflow into `spill` (the four-wide walk: the LDS part covers the usual
-  // height, the worst case is three parked children per level)
-  RTX_DEV void push(int& sp, int v) const {
-    if (sp < limit) base[sp * stride] = v; else spill[(size_t)(sp - limit) * spill_stride] = v;
-    ++sp;
-  }
-  RTX_DEV int pop(int& sp) const {
-    --sp;
-    return sp < limit ? base[sp * stride] : spill[(size_t)(sp - limit) * spill_stride];
-  }
+  RTX_DEV void push(int& sp, int v) const { base[sp * stride] = v; ++sp; }
+  RTX_DEV int pop(int& sp) const { --sp; return base[sp * stride]; }
+  RTX_DEV void put(int i, int v) const { base[i * stride] = v; }
+  RTX_DEV int get(int i) const { return base[i * stride]; }
 };
+// Capacity: the host sizes the LDS part of every launch for the scene's tree.  The double-precision kernels walk the reference's
+// binary tree, one parked child per level: kStackDepth (48) words cover a median-split tree of any size the ABI accepts (2^30
+// primitives are 30 levels).  The single-precision kernels walk the eight-wide tree with walk_stack_slots(levels) words; a scene
+// whose tree is deeper than kMaxWalkLevels is refused at upload.
 
 template <class R> RTX_DEV R slab_entry(const DNode2<R>& nd, const Ray<R>& r, V3<R> inv, R t_min, R t_max, bool& ok) {
   R t0 = (nd.lo[0] - r.o.x) * inv.x, t1 = (nd.hi[0] - r.o.x) * inv.x;
@@ -395,13 +392,16 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
 // Single-precision walk over the eight-wide tree (DNode8 / DLeaf3, pt_types.hpp), cut into resumable steps so that the
 // lanes of a persistent kernel can pick up a new ray when theirs is finished.
 //   walk8_inner  fetches ONE node record (a 128-byte line), tests its eight quantised boxes, continues with the nearest
-//                child entered and parks the others on the stack, farthest first (closest hit) or in slot order (any hit);
+//                child entered and parks the others, nearest first, as ONE stack entry;
 //   walk8_leaf   fetches ONE leaf record (a 128-byte line) and tests its up to three triangles (spheres and boxes through
 //                their tables).
-// w.node is a node (>= 0), a leaf code ~leaf (< 0) or kWalkDone.  A parked entry is not re-tested against the interval the
-// hits found meanwhile have shortened (its children / primitives are).  A box is entered on a <= b: the tree's own grouping
-// may make a box flat along an axis, which must not hide its primitives.  On an exact tie in t the primitive later in the
-// reference's leaf order wins, whatever the visiting order (DScene::rank; best_p = the current winner's primitive number).
+// w.node is a node (>= 0), a leaf code ~leaf (< 0) or kWalkDone.  A stack entry is the group of siblings still to visit under
+// one node, three words: the node's inner_base, its leaf_base - n_inner, and  slots (3 bits each, next first) | remaining
+// count << 24 | n_inner << 28;  a child's code follows from its slot.  One entry per level at most, so levels + 1 entries always
+// suffice.  A parked child is not re-tested against the interval the hits found meanwhile have shortened (its children /
+// primitives are).  A box is entered on a <= b: the tree's own grouping may make a box flat along an axis, which must not hide
+// its primitives.  On an exact tie in t the primitive later in the reference's leaf order wins, whatever the visiting order
+// (DScene::rank; best_p = the current winner's primitive number).
 // ------------------------------------------------------------------------------------------
 struct Walk8 { V3<float> inv; int node, sp, best_p; };
 
@@ -417,7 +417,19 @@ RTX_DEV bool walk8_at_leaf(const Walk8& w) { return w.node < 0; }
 RTX_DEV uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
 RTX_DEV uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
-template <bool SORT> RTX_DEV void walk8_inner(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_best, Walk8& w, LaneStack st) {
+// Next parked child, or kWalkDone.
+RTX_DEV int walk8_pop(Walk8& w, LaneStack st) {
+  if (w.sp == 0) return kWalkDone;
+  const int e = 3 * (w.sp - 1);
+  const int ib = st.get(e), lb = st.get(e + 1);
+  const uint32_t pk = (uint32_t)st.get(e + 2);
+  const int slot = (int)(pk & 7u), cnt = (int)((pk >> 24) & 7u), ni = (int)(pk >> 28);
+  if (cnt <= 1) --w.sp;
+  else st.put(e + 2, (int)(((pk & 0x00ffffffu) >> 3) | ((uint32_t)(cnt - 1) << 24) | (pk & 0xf0000000u)));
+  return slot < ni ? ib + slot : ~(lb + slot);
+}
+
+RTX_DEV void walk8_inner(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_best, Walk8& w, LaneStack st) {
   const uint4* rec = reinterpret_cast<const uint4*>(sc.nodes8 + w.node);
   const uint4 h0 = rec[0], h1 = rec[1], h2 = rec[2], h3 = rec[3];
   const uint2 h4 = *reinterpret_cast<const uint2*>(rec + 4);
@@ -428,9 +440,10 @@ template <bool SORT> RTX_DEV void walk8_inner(const DScene<float>& sc, const Ray
   const float bx = (__uint_as_float(h0.x) - r.o.x) * w.inv.x, by = (__uint_as_float(h0.y) - r.o.y) * w.inv.y, bz = (__uint_as_float(h0.z) - r.o.z) * w.inv.z;
   const uint32_t qlx[2] = {h1.x, h1.y}, qly[2] = {h1.z, h1.w}, qlz[2] = {h2.x, h2.y};
   const uint32_t qhx[2] = {h2.z, h2.w}, qhy[2] = {h3.x, h3.y}, qhz[2] = {h3.z, h3.w};
-  const int n_inner = (int)((exps >> 24) & 15u);
+  const int n_inner = (int)((exps >> 24) & 15u), n_child = (int)(exps >> 28) + 1;
   const int inner_base = (int)h4.x, leaf_base = (int)h4.y - n_inner;   // child k >= n_inner is leaf leaf_base + k
   uint32_t key[8];
+  int m = 0;   // children entered
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int sh = 8 * (k & 3);
@@ -441,44 +454,31 @@ template <bool SORT> RTX_DEV void walk8_inner(const DScene<float>& sc, const Ray
     t0 = fmaf((float)((qlz[k >> 2] >> sh) & 0xffu), az, bz); t1 = fmaf((float)((qhz[k >> 2] >> sh) & 0xffu), az, bz);
     a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
     a = fmaxf(a, t_min); b = fminf(b, t_best);
-    // an unused slot holds the planes (255, 0): a > b on every axis with a non-zero extent; the slot test covers flat nodes
-    const bool ok = a <= b && (((qlx[k >> 2] >> sh) & 0xffu) != 255u || ((qhx[k >> 2] >> sh) & 0xffu) != 0u);
+    const bool ok = a <= b && k < n_child;   // (an unused slot's planes (255, 0) read as the whole node under min / max)
     // sortable key: the entry distance (a positive float, whose bit pattern orders as an unsigned integer) with the slot in
     // its three lowest bits
     key[k] = ok ? ((__float_as_uint(a) & ~7u) | (uint32_t)k) : 0xffffffffu;
+    m += ok ? 1 : 0;
   }
-  auto code = [&](uint32_t kk) -> int {
-    const int k = (int)(kk & 7u);
-    return k < n_inner ? inner_base + k : ~(leaf_base + k);
-  };
-  if (SORT) {
-    // sorting network on the keys, ascending (19 compare-exchanges of one min and one max each)
+  // sorting network on the keys, ascending (19 compare-exchanges of one min and one max each)
 #define RTX_CX(i, j) { const uint32_t lo_ = umin_(key[i], key[j]); key[j] = umax_(key[i], key[j]); key[i] = lo_; }
-    RTX_CX(0, 1) RTX_CX(2, 3) RTX_CX(4, 5) RTX_CX(6, 7)
-    RTX_CX(0, 2) RTX_CX(1, 3) RTX_CX(4, 6) RTX_CX(5, 7)
-    RTX_CX(1, 2) RTX_CX(5, 6) RTX_CX(0, 4) RTX_CX(3, 7)
-    RTX_CX(1, 5) RTX_CX(2, 6)
-    RTX_CX(1, 4) RTX_CX(3, 6)
-    RTX_CX(2, 4) RTX_CX(3, 5)
-    RTX_CX(3, 4)
+  RTX_CX(0, 1) RTX_CX(2, 3) RTX_CX(4, 5) RTX_CX(6, 7)
+  RTX_CX(0, 2) RTX_CX(1, 3) RTX_CX(4, 6) RTX_CX(5, 7)
+  RTX_CX(1, 2) RTX_CX(5, 6) RTX_CX(0, 4) RTX_CX(3, 7)
+  RTX_CX(1, 5) RTX_CX(2, 6)
+  RTX_CX(1, 4) RTX_CX(3, 6)
+  RTX_CX(2, 4) RTX_CX(3, 5)
+  RTX_CX(3, 4)
 #undef RTX_CX
-#pragma unroll
-    for (int j = 7; j >= 1; --j)
-      if (key[j] != 0xffffffffu) st.push(w.sp, code(key[j]));
-    int go = key[0] != 0xffffffffu ? code(key[0]) : kWalkDone;
-    if (go == kWalkDone && w.sp > 0) go = st.pop(w.sp);
-    w.node = go;
-  } else {
-    int go = kWalkDone;
-#pragma unroll
-    for (int j = 7; j >= 0; --j)
-      if (key[j] != 0xffffffffu) {
-        if (go != kWalkDone) st.push(w.sp, go);
-        go = code(key[j]);
-      }
-    if (go == kWalkDone && w.sp > 0) go = st.pop(w.sp);
-    w.node = go;
+  if (m >= 2) {   // park the siblings of the nearest child as one entry (slots beyond the count are never read)
+    const uint32_t slots = (key[1] & 7u) | ((key[2] & 7u) << 3) | ((key[3] & 7u) << 6) | ((key[4] & 7u) << 9) | ((key[5] & 7u) << 12) | ((key[6] & 7u) << 15) |
+                           ((key[7] & 7u) << 18);
+    const int e = 3 * w.sp;
+    st.put(e, inner_base); st.put(e + 1, leaf_base); st.put(e + 2, (int)(slots | ((uint32_t)(m - 1) << 24) | ((uint32_t)n_inner << 28)));
+    ++w.sp;
   }
+  if (m >= 1) { const int k = (int)(key[0] & 7u); w.node = k < n_inner ? inner_base + k : ~(leaf_base + k); }
+  else w.node = walk8_pop(w, st);
 }
 
 // Möller-Trumbore on in-place vertices (ref: engine/primitives.hpp:78-110); NaN vertices fail the first comparison.
@@ -525,7 +525,7 @@ template <bool ANY> RTX_DEV void walk8_leaf(const DScene<float>& sc, const Ray<f
     if (changed && !(trial.t == c.t && w.best_p >= 0 && sc.rank[p] < sc.rank[w.best_p])) { c = trial; w.best_p = p; }
   }
   if (ANY && c.type >= 0) { w.node = kWalkDone; return; }
-  w.node = w.sp > 0 ? st.pop(w.sp) : kWalkDone;
+  w.node = walk8_pop(w, st);
 }
 
 template <bool ANY> RTX_DEV bool walk8(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, LaneStack st) {
@@ -538,7 +538,7 @@ template <bool ANY> RTX_DEV bool walk8(const DScene<float>& sc, const Ray<float>
 #ifdef RTX_WALK_STATS
     ++walk_steps;
 #endif
-    if (w.node >= 0) walk8_inner<!ANY>(sc, r, t_min, c.t, w, st);
+    if (w.node >= 0) walk8_inner(sc, r, t_min, c.t, w, st);
     else { walk8_leaf<ANY>(sc, r, t_min, c, w, st); if (ANY && c.type >= 0) return true; }
   }
 #ifdef RTX_WALK_STATS

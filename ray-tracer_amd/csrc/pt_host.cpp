@@ -32,7 +32,7 @@ void DeviceBuffer::release() {
   ptr = nullptr; cap = 0;
 }
 void WavefrontPool::release() {
-  state.release(); queues.release(); control.release(); spill.release();
+  state.release(); queues.release(); control.release(); sort_tmp.release();
   for (hipEvent_t e : events) (void)hipEventDestroy(e);
   events.clear(); events_used = 0;
 }
@@ -414,8 +414,14 @@ int HostScene::upload(const rtx_scene_desc& d, std::string& err) {
       std::string berr;
       const int rc = build_wide_tree(dev_f, d_dead, wide, berr);
       if (rc != RTX_OK) { release(); err = berr; return rc; }
+      if (wide.levels > kMaxWalkLevels) {
+        err = "the traversal tree of this scene is " + std::to_string(wide.levels) + " levels deep (at most " + std::to_string(kMaxWalkLevels) + " are walked)";
+        release();
+        return RTX_ERR_UNSUPPORTED;
+      }
       dev_f.nodes8 = (const DNode8*)wide.nodes.ptr; dev_f.leaves3 = (const DLeaf3*)wide.leaves.ptr;
       dev_f.n_nodes8 = wide.n_nodes; dev_f.n_leaves3 = wide.n_leaves; dev_f.walk_levels = wide.levels;
+      for (int a = 0; a < 3; ++a) { dev_f.bb_lo[a] = wide.lo[a]; dev_f.bb_scale[a] = wide.hi[a] > wide.lo[a] ? 128.0f / (wide.hi[a] - wide.lo[a]) : 0.f; }
     }
     lap("eight-wide tree (GPU)");
   }

@@ -45,6 +45,7 @@ struct HostBvh {
 struct WideTree {
   DeviceBuffer nodes, leaves;   // DNode8 / DLeaf3 records
   int n_nodes = 0, n_leaves = 0, levels = 0;
+  float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};   // the root's box
   double seconds = 0.0;         // device + host time of the build
   void release() { nodes.release(); leaves.release(); n_nodes = n_leaves = levels = 0; }
 };
@@ -112,7 +113,8 @@ void launch_zero_words(uint32_t* p, unsigned n, hipStream_t stream);   // p[0 ..
 
 // Wavefront pipeline (wavefront.hip): queue storage + the per-iteration launch loop.
 struct WavefrontPool {
-  DeviceBuffer state, queues, control, spill;
+  DeviceBuffer state, queues, control, sort_tmp;
+  bool sort_rays = false;   // this render sorts its ray queues before the traversal kernels take them
   // HIP events around every launch of the closest-hit traversal kernel of the last render (pairs: before, after)
   std::vector<hipEvent_t> events;
   size_t events_used = 0;

@@ -9,15 +9,10 @@ namespace rtx {
 // Dynamic LDS of a workgroup: [material table (when staged)] [traversal stacks, [level][lane]].
 extern __shared__ int lds_dyn[];
 
-// The first `limit` levels of a lane's traversal stack live in LDS; deeper ones in the scene's per-launch spill buffer (present
-// whenever the tree can need them: DScene::walk_spill).
-template <class R> RTX_DEV LaneStack lane_stack(const DScene<R>& sc, int first_int, int limit = kStackDepth) {
+RTX_DEV LaneStack lane_stack(int first_int) {
   LaneStack st;
   st.base = lds_dyn + first_int + threadIdx.x;
   st.stride = blockDim.x;
-  st.limit = limit;
-  st.spill = sc.walk_spill ? sc.walk_spill + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) : nullptr;
-  st.spill_stride = sc.walk_spill_stride;
   return st;
 }
 
@@ -90,7 +85,7 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? (INTEG == INTEG_PATHPH
   const uint32_t n_items = npix * (uint32_t)P.n_chunks;
   const uint32_t stride = gridDim.x * blockDim.x;
   uint32_t next = blockIdx.x * blockDim.x + threadIdx.x;
-  LaneStack st = lane_stack(sc, stack_first_int);
+  LaneStack st = lane_stack(stack_first_int);
 
   // Statistics: every trip adds the number of active lanes to wave-uniform counters.  A lane
   // that leaves the loop stops adding, so the lane that stays longest holds the wave's totals:
@@ -224,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void trace_fast_kernel(DScene<R> sc, const 
   const double* q = rays8 + i * 8ull;
   Ray<R> r = {{R(q[0]), R(q[1]), R(q[2])}, {R(q[3]), R(q[4]), R(q[5])}};
   Hit<R> h;
-  bool ok = trace_closest<R, MODE>(sc, r, R(q[6]), R(q[7]), h, lane_stack(sc, 0));
+  bool ok = trace_closest<R, MODE>(sc, r, R(q[6]), R(q[7]), h, lane_stack(0));
   DHitOut o;
   o.hit = ok; o.prim_type = ok ? h.type : -1; o.prim_index = ok ? h.idx : -1;
   o.material_id = ok ? h.mat : 0; o.front_face = ok ? h.front : 0; o.pad = 0;

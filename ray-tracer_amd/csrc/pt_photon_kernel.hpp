@@ -11,7 +11,7 @@ __global__ __launch_bounds__(kBlock) void photon_trace_kernel(DScene<R> sc, DRen
                                                               const int32_t* __restrict__ targets, int n_targets, uint32_t n_photons, R* __restrict__ out,
                                                               DCounters* __restrict__ counters, int stack_first_int) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  LaneStack st = lane_stack(sc, stack_first_int);
+  LaneStack st = lane_stack(stack_first_int);
   uint32_t n_closest = 0;
   if (i < n_photons) {
     const size_t n = n_photons;

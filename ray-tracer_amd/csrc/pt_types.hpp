@@ -62,8 +62,12 @@ struct alignas(128) DLeaf3 {
 };
 constexpr int kLeafMaxPrims = 3;
 constexpr int kWalkDone = 0x7fffffff;
-// Levels of a walk's stack kept in LDS by the queue-based traversal kernels; deeper levels spill to global memory.
-constexpr int kWalkLdsLevels = 12;
+// Words of stack a walk of a tree of `levels` node levels can need: one three-word entry per level, and one to spare.
+constexpr int walk_stack_slots(int levels) { return 3 * (levels + 1); }
+// Deepest eight-wide tree the kernels walk: its stack (120 words per lane) still fits the LDS of one 256-lane workgroup.  A soup of
+// 10 M triangles builds 8 levels; cuts at Morton code bits consume at least one bit of the 63 per level before ranges of equal
+// codes are halved, so only adversarial inputs get anywhere near.
+constexpr int kMaxWalkLevels = 39;
 // Shading record of one primitive of a flat scene, in the order the flat intersection tests them (spheres in the
 // reference's leaf order, planes, quad lights, disk lights): what the winner's normal and material need, fetched
 // once per hit instead of being carried through every test.  sphere: (a,b,c) = centre, w = 1 / radius; others:
@@ -87,9 +91,7 @@ template <class R> struct DScene {
   const DNode8* nodes8; const DLeaf3* leaves3;         // single-precision traversal layout (NULL in the double scene and for scenes tested linearly)
   const int32_t* rank;                                 // position of every bounded primitive (numbered as DLeaf3::id) in the reference's leaf order
   const DFlatRec* flat;                                // flat scenes only (single precision)
-  // Overflow levels of the eight-wide walk's per-lane stack, [level][lane of the grid], set per launch by the host when the tree
-  // is deeper than the LDS part holds: a walk parks at most 7 siblings per level, so 7 * levels + 1 entries always suffice.
-  int32_t* walk_spill; int32_t walk_spill_stride;
+  float bb_lo[3], bb_scale[3];                         // the eight-wide tree's root box as a 128^3 grid: cell = (p - bb_lo) * bb_scale (ray sorting)
   int32_t n_spheres, n_planes, n_tris, n_boxes, n_points, n_quads, n_disks, n_mats, n_images, n_emissive;
   int32_t n_nodes, n_prims, n_nodes8, n_leaves3, walk_levels;
   int32_t n_nmaps;                                     // materials with a normal map (picks the kernel instances that apply them)

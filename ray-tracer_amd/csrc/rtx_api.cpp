@@ -81,6 +81,8 @@ unsigned char* scratch_pointer(int device) {
 }
 }  // namespace
 
+struct rtx_ctx;
+static size_t stack_words(const rtx_ctx* c, bool f64);
 struct rtx_ctx {
   int device = 0;
   unsigned char* scratch_dev = nullptr;   // this device's copy of `scratch`
@@ -92,23 +94,16 @@ struct rtx_ctx {
   DCamera<float> cam_f;
   DCamera<double> cam_d;
   DeviceBuffer partial, film, counters, rays, hits, post_in, post_out, bdpt_store;
-  DeviceBuffer walk_spill;   // overflow levels of the eight-wide walk's stacks for the launch in flight (deep trees only)
   DeviceBuffer ph_lights, ph_targets, ph_out, ph_nodes, ph_data, ph_boxes;   // PathPhoton: photon pass plan, its raw output, the kd-tree
   WavefrontPool wf;         // wavefront-pipeline queues, allocated on first use
 };
 
-// A walk of the eight-wide tree parks at most seven siblings per level: 7 * levels + 1 stack entries always suffice.  The kernels
-// keep the first `lds_levels` of them in LDS; where the tree is deeper, the rest goes to a buffer of `lanes` columns handed over
-// in the scene record of the launch.
-static bool set_walk_spill(rtx_ctx* c, DScene<float>& sc, size_t lanes, int lds_levels) {
-  sc.walk_spill = nullptr; sc.walk_spill_stride = 0;
-  const int need = 7 * sc.walk_levels + 1;
-  if (sc.n_nodes8 == 0 || need <= lds_levels) return true;
-  if (lanes > 0x7fffffffull || !c->walk_spill.ensure(lanes * (size_t)(need - lds_levels) * sizeof(int))) return false;
-  sc.walk_spill = (int32_t*)c->walk_spill.ptr; sc.walk_spill_stride = (int32_t)lanes;
-  return true;
+// Words of LDS per lane the traversal stack of a launch needs (0: the scene is tested linearly): the double-precision kernels
+// walk the reference's binary tree (kStackDepth), the single-precision ones the eight-wide tree (one three-word entry per level).
+static size_t stack_words(const rtx_ctx* c, bool f64) {
+  if (c->scene.n_prims <= kLinearMaxPrims) return 0;
+  return f64 ? (size_t)kStackDepth : (size_t)walk_stack_slots(c->scene.wide.levels);
 }
-static bool set_walk_spill(rtx_ctx*, DScene<double>&, size_t, int) { return true; }   // the binary tree's depth fits the LDS part
 
 // PathPhoton: the caustic photon pass (ref: engine/renderer.cpp:344-372, engine/photon_integrator.hpp:93-137) — plan the
 // photons per emissive sphere on the host, trace them on the GPU, build the kd-tree on the host as PhotonMap::build does
@@ -133,7 +128,7 @@ void photon_build_tree(PhotonKey* ph, size_t start, size_t end, int depth) {
     photon_build_tree(ph, mid + 1, end, depth + 1);
   }
 }
-template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderParams& P, DScene<R> sc, size_t lds_bytes, hipStream_t stream) {
+template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderParams& P, const DScene<R>& sc, size_t lds_bytes, hipStream_t stream) {
   const double kPi = 3.14159265358979323846;
   const std::vector<rtx_sphere>& sph = c->scene.h_spheres;
   const std::vector<rtx_material>& mats = c->scene.h_materials;
@@ -173,7 +168,6 @@ template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderPar
   if (!c->ph_lights.upload(plan.data(), plan.size() * sizeof(DPhotonLight)) || !c->ph_targets.upload(targets.data(), targets.size() * sizeof(int32_t)) ||
       !c->ph_out.ensure((size_t)n * 10 * sizeof(R)))
     return fail(RTX_ERR_OUT_OF_MEMORY, "photon pass buffers (%u photons)", n);
-  if (!set_walk_spill(c, sc, ((size_t)n + kBlock - 1) / kBlock * kBlock, kStackDepth)) return fail(RTX_ERR_OUT_OF_MEMORY, "traversal stacks of the photon pass");
   launch_photon_trace(sc, P, (const DPhotonLight*)c->ph_lights.ptr, (int)plan.size(), (const int32_t*)c->ph_targets.ptr, (int)targets.size(), n, (R*)c->ph_out.ptr,
                       (DCounters*)c->counters.ptr, lds_bytes, stream);
   HIP_TRY(hipGetLastError());
@@ -279,7 +273,6 @@ int rtx_destroy(rtx_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   c->scene.release();
   c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release(); c->post_in.release(); c->post_out.release(); c->bdpt_store.release();
-  c->walk_spill.release();
   c->ph_lights.release(); c->ph_targets.release(); c->ph_out.release(); c->ph_nodes.release(); c->ph_data.release(); c->ph_boxes.release();
   c->wf.release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -402,8 +395,6 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   if (no_alloc) {
     if (f64 || mnee || bdpt || photon) return fail(RTX_ERR_UNSUPPORTED, "the no-allocation render runs single-precision PathTrace and Whitted only");
     if (pipeline != RTX_PIPELINE_FUSED) return fail(RTX_ERR_UNSUPPORTED, "the no-allocation render runs the fused pipeline only (this scene and these settings select the queue-based one)");
-    if (c->scene.wide.n_nodes > 0 && 7 * c->scene.wide.levels + 1 > kStackDepth)
-      return fail(RTX_ERR_UNSUPPORTED, "the no-allocation render holds traversal stacks in LDS only: this scene's tree has %d levels (at most %d)", c->scene.wide.levels, (kStackDepth - 1) / 7);
     static_assert(sizeof(DCounters) <= kScratchHeader, "counters must fit the scratch header");
     counters_ptr = (DCounters*)c->scratch_dev;
     partial_ptr = c->scratch_dev + kScratchHeader;
@@ -443,16 +434,16 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     if (!L.lds_mats) L.mode = MODE_TREE_UV;
     L.stack_first_int = L.lds_mats ? (int)((mat_bytes / 4 + 3) & ~(size_t)3) : 0;
     const bool stack = L.mode != MODE_FLAT && needs_stack;
-    L.lds_bytes = ((size_t)L.stack_first_int + (stack ? (size_t)kStackDepth * kBlock : 0)) * sizeof(int);
+    L.lds_bytes = ((size_t)L.stack_first_int + (stack ? stack_words(c, f64) * kBlock : 0)) * sizeof(int);
     // Persistent grid: enough workgroups to fill every CU at the kernel's occupancy, no more.
     const int blocks_per_cu = stack ? 3 : 6;
     L.grid = (int)std::min<unsigned long long>((items + kBlock - 1) / kBlock, (unsigned long long)c->n_cus * blocks_per_cu);
     int lrc;
-    DScene<float> scf = c->scene.dev_f;   // per-launch copy: carries the overflow levels of the traversal stacks
+    const DScene<float>& scf = c->scene.dev_f;
     if (photon) {   // the photon pass comes first (ref: engine/renderer.cpp:344-372); its rays are counted as closest-hit queries
       // the photon kernel is the tree-walking instance whatever the render kernel is (a flat scene of 13 to 16 spheres walks
       // its tree there), so its traversal stacks are sized from the scene alone
-      const size_t walk_lds = needs_stack ? (size_t)kStackDepth * kBlock * sizeof(int) : 0;
+      const size_t walk_lds = stack_words(c, f64) * kBlock * sizeof(int);
       const auto ph0 = std::chrono::steady_clock::now();
       const int prc = f64 ? photon_pass(c, s, P, c->scene.dev_d, walk_lds, stream) : photon_pass(c, s, P, c->scene.dev_f, walk_lds, stream);
       if (prc != RTX_OK) return prc;
@@ -467,7 +458,6 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
       const unsigned long long max_lanes = std::max<unsigned long long>(kBlock, (2ull << 30) / per_lane / kBlock * kBlock);
       if ((unsigned long long)L.grid * kBlock > max_lanes) L.grid = (int)(max_lanes / kBlock);
       if (!c->bdpt_store.ensure((size_t)((unsigned long long)L.grid * kBlock * per_lane))) return fail(RTX_ERR_OUT_OF_MEMORY, "BDPT light-vertex store (%llu bytes)", (unsigned long long)L.grid * kBlock * per_lane);
-      if (!f64 && !set_walk_spill(c, scf, (size_t)L.grid * kBlock, kStackDepth)) return fail(RTX_ERR_OUT_OF_MEMORY, "traversal stacks");
       if (f64) lrc = launch_render_bdpt(c->scene.dev_d, c->cam_d, P, (double*)partial_ptr, counters_ptr, L, (double*)c->bdpt_store.ptr, cap, stream);
       else lrc = launch_render_bdpt(scf, c->cam_f, P, (float*)partial_ptr, counters_ptr, L, (float*)c->bdpt_store.ptr, cap, stream);
       HIP_TRY(hipEventRecord(c->evm, stream));
@@ -478,7 +468,6 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
       HIP_TRY(hipEventRecord(c->evm, stream));
       launch_film_reduce((const double*)partial_ptr, d_film, npix, P.n_chunks, P.spp, stream);
     } else {
-      if (!set_walk_spill(c, scf, (size_t)L.grid * kBlock, kStackDepth)) return fail(RTX_ERR_OUT_OF_MEMORY, "traversal stacks");
       lrc = launch_render_fused(scf, c->cam_f, P, (float*)partial_ptr, counters_ptr, L, stream);
       HIP_TRY(hipEventRecord(c->evm, stream));
       launch_film_reduce((const float*)partial_ptr, d_film, npix, P.n_chunks, P.spp, stream);
@@ -487,7 +476,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     st.kernel_launches = photon ? 3 : 2;
   } else {
     std::string err;
-    int rc = wavefront_render(c->wf, c->scene.dev_f, c->cam_f, P, d_film, counters_ptr, c->n_cus, c->scene.fused_mode(false), needs_stack ? kWalkLdsLevels : 0, stream, st.kernel_launches, err);
+    int rc = wavefront_render(c->wf, c->scene.dev_f, c->cam_f, P, d_film, counters_ptr, c->n_cus, c->scene.fused_mode(false), (int)stack_words(c, false), stream, st.kernel_launches, err);
     if (rc != RTX_OK) return fail(rc, "wavefront: %s", err.c_str());
     HIP_TRY(hipEventRecord(c->evm, stream));
   }
@@ -571,14 +560,9 @@ static int trace_impl(rtx_ctx* c, const double* rays8, size_t n, rtx_hit* out, i
   HIP_TRY(hipSetDevice(c->device));
   if (!c->rays.ensure(n * 8 * sizeof(double)) || !c->hits.ensure(n * sizeof(DHitOut))) return fail(RTX_ERR_OUT_OF_MEMORY, "ray batch of %zu", n);
   HIP_TRY(hipMemcpyAsync(c->rays.ptr, rays8, n * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  const size_t lds = c->scene.n_prims > kLinearMaxPrims ? (size_t)kStackDepth * kBlock * sizeof(int) : 0;
+  const size_t lds = stack_words(c, mode != 1) * kBlock * sizeof(int);
   if (mode == 0) launch_trace_ref(c->scene.dev_d, c->scene.dev_ref, (const double*)c->rays.ptr, n, (DHitOut*)c->hits.ptr, c->stream);
-  else if (mode == 1) {
-    DScene<float> scf = c->scene.dev_f;
-    const unsigned grid = trace_fast_grid(n, c->n_cus);
-    if (!set_walk_spill(c, scf, (size_t)grid * kBlock, kStackDepth)) return fail(RTX_ERR_OUT_OF_MEMORY, "traversal stacks");
-    launch_trace_fast(scf, (const double*)c->rays.ptr, n, (DHitOut*)c->hits.ptr, c->scene.fused_mode(false) == MODE_FLAT ? MODE_FLAT : MODE_TREE_UV, lds, c->stream, c->n_cus);
-  }
+  else if (mode == 1) launch_trace_fast(c->scene.dev_f, (const double*)c->rays.ptr, n, (DHitOut*)c->hits.ptr, c->scene.fused_mode(false) == MODE_FLAT ? MODE_FLAT : MODE_TREE_UV, lds, c->stream, c->n_cus);
   else launch_trace_fast(c->scene.dev_d, (const double*)c->rays.ptr, n, (DHitOut*)c->hits.ptr, MODE_TREE_UV, lds, c->stream, c->n_cus);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, c->hits.ptr, n * sizeof(DHitOut), hipMemcpyDeviceToHost, c->stream));

@@ -16,6 +16,10 @@
 // The traversal kernels carry only a ray and a candidate, so they run at 2-4x the occupancy
 // of the fused kernel; that is what pays for the queue traffic on scenes that walk a tree.
 // Per-slot arithmetic and sample order equal the fused kernel's, so films agree to rounding.
+#include <cstring>   // rocPRIM's headers use memset without including it
+
+#include <rocprim/rocprim.hpp>
+
 #include "pt_kernels.hpp"
 #include "pt_host.hpp"
 
@@ -36,19 +40,16 @@ struct WfArrays {
   uint32_t* sh_slot;
   float* sh[7];                       // origin, direction, t_max
   float* sh_c[3];
+  // Ray sorting (scenes that walk a tree): keys and queue entries before and after the radix sort.  The traversal kernels take
+  // their rays in the order of order_out, so that the lanes of a wave - and the waves in flight at any moment - start in the same
+  // corner of the scene and fetch the same node and leaf records.
+  uint32_t *key_in, *key_out, *order_in, *order_out;
   uint32_t n_slots;
 };
 
 struct WfControl { uint32_t n_q[2]; uint32_t n_shadow; uint32_t cursor; };   // cursor: next queue entry a persistent kernel hands out
 
-// A persistent traversal wave refills its idle lanes when fewer than this many are walking
-// (10 M triangles, 16 spp, with the 64-byte records: 8: 240 ms, 16: 202, 24: 200, 32: 201, 40: 212, 48: 255, 56: 386).
-#ifndef RTX_REFILL_BELOW
-#define RTX_REFILL_BELOW 24
-#endif
-constexpr int kRefillBelow = RTX_REFILL_BELOW;
-// ... and runs the leaf phase when at least this many lanes have a leaf pending (with refill below 24:
-// 2: 195 ms, 4: 197, 8: 200; 16 and 24 slower still).
+// A persistent traversal wave runs the leaf phase when at least this many lanes have a leaf pending.
 #ifndef RTX_LEAF_BATCH
 #define RTX_LEAF_BATCH 2
 #endif
@@ -57,7 +58,7 @@ constexpr int kLeafBatch = RTX_LEAF_BATCH;
 #ifndef RTX_POOL_MULT
 #define RTX_POOL_MULT 128   // path slots per resident lane (164 B each: 11 GB at most on 256 CUs); 10 M triangles at 1080p x 64 spp: 16: 839 ms, 32: 762, 64 and up (every work item in flight): 721
 #endif
-constexpr int kWfArrays = 6 + 3 + 3 + 3 + 1 + 7 + 3 + 2 + 2 + 1 + 7 + 3;   // 4-byte arrays of n_slots entries
+constexpr int kWfArrays = 6 + 3 + 3 + 3 + 1 + 7 + 3 + 2 + 2 + 1 + 7 + 3 + 4;   // 4-byte arrays of n_slots entries
 
 // Append to a queue from (possibly divergent) code: the active lanes of the wave take
 // consecutive entries with one atomic.
@@ -69,20 +70,6 @@ RTX_DEV uint32_t wave_append(uint32_t* counter) {
   if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
   base = (uint32_t)__shfl((int)base, leader, 64);
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-}
-
-// The lanes for which `want` holds take consecutive entries of a queue of n through the shared
-// cursor (one atomic per wave); returns the entry, or 0xffffffff when the queue is used up.
-RTX_DEV uint32_t wave_take(uint32_t* cursor, bool want, uint32_t n) {
-  const unsigned long long mask = __ballot(want);
-  if (mask == 0ull) return 0xffffffffu;
-  const int lane = (int)(threadIdx.x & 63);
-  const int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(mask));
-  base = (uint32_t)__shfl((int)base, leader, 64);
-  const uint32_t mine = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  return want && mine < n ? mine : 0xffffffffu;
 }
 
 // Workgroup-level forms for kernels whose every thread reaches the call (they synchronise the
@@ -196,6 +183,43 @@ __global__ __launch_bounds__(kStreamBlock) void wf_generate(DCamera<float> cam, 
   block_count2(bs, &counters->closest, live, &counters->samples, started);
 }
 
+// Sort key of a ray: the Morton code of its origin's cell in a 128^3 grid over the tree's bounding box (21 bits) above the
+// octant of its direction (3 bits).  Entries past the queue's end get the largest key and stay at the end (the sort is stable).
+RTX_DEV uint32_t spread7(uint32_t v) {   // 7 bits -> every third bit
+  v &= 0x7fu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+RTX_DEV uint32_t ray_sort_key(const DScene<float>& sc, V3<float> o, V3<float> d) {
+  const float gx = fminf(fmaxf((o.x - sc.bb_lo[0]) * sc.bb_scale[0], 0.f), 127.f), gy = fminf(fmaxf((o.y - sc.bb_lo[1]) * sc.bb_scale[1], 0.f), 127.f),
+              gz = fminf(fmaxf((o.z - sc.bb_lo[2]) * sc.bb_scale[2], 0.f), 127.f);
+  const uint32_t m = (spread7((uint32_t)gx) << 2) | (spread7((uint32_t)gy) << 1) | spread7((uint32_t)gz);
+  const uint32_t oct = (d.x < 0.f ? 4u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 1u : 0u);
+  return (m << 3) | oct;
+}
+constexpr unsigned kSortKeyBits = 24;
+
+// shadow = 0: the ray queue q (entries = path slots); shadow = 1: the shadow-ray queue (entries = its own indices)
+__global__ __launch_bounds__(256) void wf_sort_keys(DScene<float> sc, WfArrays A, const WfControl* __restrict__ ctl, int q, int shadow, uint32_t bound) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bound) return;
+  const uint32_t n = shadow ? ctl->n_shadow : ctl->n_q[q];
+  uint32_t key = 0xffffffffu, entry = 0u;
+  if (i < n) {
+    if (shadow) {
+      entry = i;
+      key = ray_sort_key(sc, V3<float>{A.sh[0][i], A.sh[1][i], A.sh[2][i]}, V3<float>{A.sh[3][i], A.sh[4][i], A.sh[5][i]});
+    } else {
+      entry = A.q[q][i];
+      key = ray_sort_key(sc, V3<float>{A.ray[0][entry], A.ray[1][entry], A.ray[2][entry]}, V3<float>{A.ray[3][entry], A.ray[4][entry], A.ray[5][entry]});
+    }
+  }
+  A.key_in[i] = key; A.order_in[i] = entry;
+}
+
 // Both traversal kernels are persistent: a launch holds as many lanes as the chip keeps
 // resident, every lane walks one ray at a time in resumable steps and takes its next queue
 // entry (grid-stride) when its ray is finished, so a wave is not held back by its longest
@@ -204,13 +228,50 @@ __global__ __launch_bounds__(kStreamBlock) void wf_generate(DCamera<float> cam, 
 __device__ unsigned long long g_walk_stats[8];   // diagnostic build only
 #endif
 
+// A wave takes its queue entries in chunks: one atomic on the shared cursor per kFeedChunk entries instead of one per refill.
+// All fields are the same in every lane.
+constexpr uint32_t kFeedChunk = 256;
+struct WaveFeed { uint32_t next, end; bool dry; };
+
+// Entry of the queue of n for each lane with `want` (0xffffffff once the queue is used up); every lane of the wave calls it.
+RTX_DEV uint32_t feed_take(WaveFeed& f, uint32_t* cursor, bool want, uint32_t n) {
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0ull) return 0xffffffffu;
+  const int lane = (int)(threadIdx.x & 63);
+  const uint32_t need = (uint32_t)__popcll(mask), rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  uint32_t got = 0xffffffffu;
+  const uint32_t avail = f.end - f.next, served = avail < need ? avail : need;
+  if (want && rank < served) got = f.next + rank;
+  f.next += served;
+  if (served < need && !f.dry) {
+    uint32_t base = 0u;
+    if (lane == 0) base = atomicAdd(cursor, kFeedChunk);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    f.dry = base >= n;
+    f.next = f.dry ? n : base;
+    f.end = f.dry ? n : (base + kFeedChunk < n ? base + kFeedChunk : n);
+    const uint32_t avail2 = f.end - f.next, rest = need - served, served2 = avail2 < rest ? avail2 : rest;
+    if (want && rank >= served && rank - served < served2) got = f.next + (rank - served);
+    f.next += served2;
+  }
+  return got;
+}
+
+// How many lanes of a wave must be without a ray before it stops to hand out new ones (storing results, promoting the prefetched
+// rays and prefetching again costs the whole wave some sixty instructions).
+#ifndef RTX_REFILL_IDLE
+#define RTX_REFILL_IDLE 16   // 10 M triangles, 16 spp: 1: 207 ms, 8: 163, 16: 151, 32: 152
+#endif
+
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int q, int stack_levels, DCounters* counters) {
+__global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int q, int stack_levels, DCounters* counters,
+                                                    const uint32_t* __restrict__ order /* the queue's entries in the order to take them */) {
   const uint32_t n = ctl->n_q[q];
-  uint32_t n_nodes = 0, n_prims = 0;   // node records and leaf primitives this lane tested
-  bool more = true;   // wave-uniform: the queue may still have entries
-  LaneStack st = lane_stack(sc, 0, stack_levels);
+  uint32_t n_nodes = 0, n_prims = 0;   // node records and leaf records this lane fetched
+  WaveFeed feed = {0u, 0u, false};
+  LaneStack st = lane_stack(0);
   const bool tree = MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims;
+  // the ray being walked
   uint32_t slot = 0;
   Ray<float> ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
   Cand<float> c;
@@ -218,10 +279,16 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A
   cand_init(c, 1e9f);
   w.node = kWalkDone; w.sp = 0; w.best_p = -1; w.inv = {0.f, 0.f, 0.f};
   int state = 0;   // 0 no ray, 1 walking, 2 walk finished, result not yet stored
+  // the next ray, loaded while the current one is walked, so that a lane changes rays without waiting on memory
+  uint32_t nslot = 0;
+  Ray<float> nray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
+  bool have_next = false;
   for (;;) {
-    // Refill in batches: finished lanes wait until enough of the wave is idle, then store their
-    // hits and fetch together.
-    if (__popcll(__ballot(state == 1)) < kRefillBelow) {
+    const int walking = __popcll(__ballot(state == 1));
+    if (64 - walking >= RTX_REFILL_IDLE || walking == 0) {
+#ifdef RTX_WALK_STATS
+      { const unsigned long long ms = __ballot(state == 2); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_walk_stats[5], 1ull); atomicAdd(&g_walk_stats[6], (unsigned long long)__popcll(ms)); } }
+#endif
       if (state == 2) {
         int id = -1, uv = 0;
         float t = 0.f, ua = 0.f, ub = 0.f;
@@ -236,17 +303,20 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A
         if constexpr (MODE == MODE_TREE_UV) { A.hit_ua[slot] = ua; A.hit_ub[slot] = ub; A.hit_uv[slot] = uv; }
         state = 0;
       }
-      const uint32_t e = more ? wave_take(&ctl->cursor, state == 0, n) : 0xffffffffu;
-      more = __ballot(e != 0xffffffffu) != 0ull;
-      if (e != 0xffffffffu) {
-        slot = A.q[q][e];
-        ray.o = {A.ray[0][slot], A.ray[1][slot], A.ray[2][slot]};
-        ray.d = {A.ray[3][slot], A.ray[4][slot], A.ray[5][slot]};
+      if (state == 0 && have_next) {   // take over the prefetched ray
+        slot = nslot; ray = nray;
         cand_init(c, 1e9f);
         if (tree) walk8_begin(w, ray);
-        state = 1;
+        state = 1; have_next = false;
       }
-      if (__ballot(state == 1) == 0ull) break;
+      const uint32_t e = feed_take(feed, &ctl->cursor, !have_next, n);
+      if (e != 0xffffffffu) {
+        nslot = order[e];
+        nray.o = {A.ray[0][nslot], A.ray[1][nslot], A.ray[2][nslot]};
+        nray.d = {A.ray[3][nslot], A.ray[4][nslot], A.ray[5][nslot]};
+        have_next = true;
+      }
+      if (__ballot(state == 1 || have_next) == 0ull) break;
     }
     if constexpr (MODE == MODE_FLAT) {
       if (state == 1) state = 2;
@@ -257,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A
 #ifdef RTX_WALK_STATS
       { const unsigned long long mi = __ballot(inner); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_walk_stats[0], 1ull); if (mi) { atomicAdd(&g_walk_stats[1], 1ull); atomicAdd(&g_walk_stats[2], (unsigned long long)__popcll(mi)); } } }
 #endif
-      if (inner) { walk8_inner<true>(sc, ray, 0.001f, c.t, w, st); ++n_nodes; }
+      if (inner) { walk8_inner(sc, ray, 0.001f, c.t, w, st); ++n_nodes; }
       // leaves wait until a batch of lanes has one, or until no lane has an inner node left
       const bool leaf = state == 1 && walk8_at_leaf(w);
       if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
@@ -343,10 +413,11 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DRend
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int stack_levels) {
+__global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int stack_levels,
+                                                     const uint32_t* __restrict__ order /* shadow-queue indices in the order to take them, or NULL = as queued */) {
   const uint32_t n = ctl->n_shadow;
-  bool more = true;   // wave-uniform: the queue may still have entries
-  LaneStack st = lane_stack(sc, 0, stack_levels);
+  WaveFeed feed = {0u, 0u, false};
+  LaneStack st = lane_stack(0);
   const bool tree = MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims;
   uint32_t i = 0;
   float t_max = 0.f;
@@ -356,27 +427,33 @@ __global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays 
   cand_init(c, 1e9f);
   w.node = kWalkDone; w.sp = 0; w.best_p = -1; w.inv = {0.f, 0.f, 0.f};
   int state = 0;   // 0 no ray, 1 walking, 2 finished (occluded), 3 finished (visible)
+  uint32_t ni = 0;   // the next shadow ray, loaded while the current one is walked
+  float nt_max = 0.f;
+  Ray<float> nsr = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
+  bool have_next = false;
   for (;;) {
-    if (__popcll(__ballot(state == 1)) < kRefillBelow) {
+    const int walking = __popcll(__ballot(state == 1));
+    if (64 - walking >= RTX_REFILL_IDLE || walking == 0) {
       if (state == 3) {
         const uint32_t slot = A.sh_slot[i];   // at most one shadow ray per slot per iteration: no atomics needed
         A.acc[0][slot] += A.sh_c[0][i]; A.acc[1][slot] += A.sh_c[1][i]; A.acc[2][slot] += A.sh_c[2][i];
       }
       if (state != 1) state = 0;
-      {
-        const uint32_t e = more ? wave_take(&ctl->cursor, state == 0, n) : 0xffffffffu;
-        more = __ballot(e != 0xffffffffu) != 0ull;
-        if (e != 0xffffffffu) {
-          i = e;
-          sr.o = {A.sh[0][i], A.sh[1][i], A.sh[2][i]};
-          sr.d = {A.sh[3][i], A.sh[4][i], A.sh[5][i]};
-          t_max = A.sh[6][i];
-          cand_init(c, t_max);
-          if (tree) walk8_begin(w, sr);
-          state = 1;
-        }
+      if (state == 0 && have_next) {
+        i = ni; sr = nsr; t_max = nt_max;
+        cand_init(c, t_max);
+        if (tree) walk8_begin(w, sr);
+        state = 1; have_next = false;
       }
-      if (__ballot(state == 1) == 0ull) break;
+      const uint32_t e = feed_take(feed, &ctl->cursor, !have_next, n);
+      if (e != 0xffffffffu) {
+        ni = order ? order[e] : e;
+        nsr.o = {A.sh[0][ni], A.sh[1][ni], A.sh[2][ni]};
+        nsr.d = {A.sh[3][ni], A.sh[4][ni], A.sh[5][ni]};
+        nt_max = A.sh[6][ni];
+        have_next = true;
+      }
+      if (__ballot(state == 1 || have_next) == 0ull) break;
     }
     if constexpr (MODE == MODE_FLAT) {
       if (state == 1) state = flat_occluded(sc, sr, 0.001f, t_max) ? 2 : 3;
@@ -384,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays 
       if (state == 1) state = occluded(sc, sr, 0.001f, t_max, st) ? 2 : 3;
     } else {
       const bool inner = state == 1 && walk8_at_inner(w);
-      if (inner) walk8_inner<false>(sc, sr, 0.001f, c.t, w, st);
+      if (inner) walk8_inner(sc, sr, 0.001f, c.t, w, st);
       const bool leaf = state == 1 && walk8_at_leaf(w);
       if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
         if (leaf) walk8_leaf<true>(sc, sr, 0.001f, c, w, st);
@@ -397,17 +474,24 @@ __global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays 
 template <int MODE> void launch_iteration_kernels(const DScene<float>& sc_in, const DCamera<float>& cam, const DRenderParams& P, const WfArrays& A, WfControl* ctl,
                                                   float* partial, DCounters* counters, bool lds_mats, size_t mat_lds, int stack_levels, unsigned grid,
                                                   unsigned resident_blocks, int step /*0 first generate, 1 shade, 2 connect, 3 generate*/, int qa, int qb,
-                                                  hipStream_t stream, uint32_t& launches, int* spill, WavefrontPool& pool) {
-  // the persistent traversal kernels take the overflow levels of their stacks through the scene record, [level][lane of the grid]
-  DScene<float> sc = sc_in;
-  sc.walk_spill = spill; sc.walk_spill_stride = (int32_t)((grid < resident_blocks ? grid : resident_blocks) * (unsigned)kBlock);
+                                                  hipStream_t stream, uint32_t& launches, WavefrontPool& pool) {
+  const DScene<float>& sc = sc_in;
   const dim3 g((grid + (kStreamBlock / kBlock) - 1) / (kStreamBlock / kBlock)), bs(kStreamBlock), b(kBlock);   // `grid` counts kBlock-sized groups
   const dim3 gw(grid < resident_blocks ? grid : resident_blocks);   // persistent traversal kernels
   const size_t walk_lds = MODE == MODE_FLAT ? 0 : (size_t)stack_levels * kBlock * sizeof(int);
+  const bool sorted = pool.sort_rays && MODE != MODE_FLAT && sc.n_nodes8 > 0;
+  const uint32_t bound = grid * (unsigned)kBlock < A.n_slots ? grid * (unsigned)kBlock : A.n_slots;   // the queues are no longer than this
+  auto sort_queue = [&](int q, int shadow) {
+    hipLaunchKernelGGL(wf_sort_keys, dim3((bound + 255) / 256), dim3(256), 0, stream, sc, A, ctl, q, shadow, bound);
+    size_t bytes = pool.sort_tmp.cap;
+    (void)rocprim::radix_sort_pairs(pool.sort_tmp.ptr, bytes, A.key_in, A.key_out, A.order_in, A.order_out, (size_t)bound, 0u, kSortKeyBits, stream);
+    launches += 2;
+  };
   if (step == 0 || step == 3) {
     hipLaunchKernelGGL(wf_generate, g, bs, 0, stream, cam, P, A, ctl, step == 0 ? 1 : 0, qa, qb, partial, counters);
+    if (sorted) sort_queue(qb, 0);
     pool.mark(stream);
-    hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, qb, stack_levels, counters);
+    hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, qb, stack_levels, counters, sorted ? A.order_out : A.q[qb]);
     pool.mark(stream);
     ++launches;
   } else if (step == 1) {
@@ -416,8 +500,10 @@ template <int MODE> void launch_iteration_kernels(const DScene<float>& sc_in, co
       else hipLaunchKernelGGL((wf_shade<MODE, false, MODE == MODE_TREE_UV>), g, bs, 0, stream, sc, P, A, ctl, qa, counters);
     } else if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, P, A, ctl, qa, counters);
     else hipLaunchKernelGGL((wf_shade<MODE, false>), g, bs, 0, stream, sc, P, A, ctl, qa, counters);
-  } else
-    hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, stack_levels);
+  } else {
+    if (sorted) sort_queue(0, 1);
+    hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, stack_levels, sorted ? A.order_out : nullptr);
+  }
 }
 
 // Blocks of the traversal kernels one CU keeps resident (the smaller of the two kernels' figures).
@@ -459,8 +545,18 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
     A.sh_slot = nextu();
     for (auto& p : A.sh) p = nextf();
     for (auto& p : A.sh_c) p = nextf();
+    A.key_in = nextu(); A.key_out = nextu(); A.order_in = nextu(); A.order_out = nextu();
     A.n_slots = n_slots;
     if (k != (size_t)kWfArrays) { err = "internal: array count"; return RTX_ERR_INVALID_ARGUMENT; }
+  }
+  // Sorting the ray queues by origin cell and direction octant before each traversal launch is off by default: measured on a 10 M
+  // triangle soup, the closest-hit kernel took the same time (it is bound by vector-ALU issue, not by the lines it fetches) and the
+  // sorts added 68 ms to a 608 ms frame.  RTX_RAY_SORT=1 switches it on (experiments only; films do not depend on it).
+  pool.sort_rays = sc.n_nodes8 > 0 && mode != MODE_FLAT && getenv("RTX_RAY_SORT") != nullptr;
+  if (pool.sort_rays) {
+    size_t bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, bytes, A.key_in, A.key_out, A.order_in, A.order_out, (size_t)n_slots, 0u, kSortKeyBits, stream) != hipSuccess ||
+        !pool.sort_tmp.ensure(bytes)) { err = "pool allocation (ray sort)"; return RTX_ERR_OUT_OF_MEMORY; }
   }
   WfControl* ctl = (WfControl*)pool.control.ptr;
   float* partial = (float*)pool.queues.ptr;
@@ -471,18 +567,11 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   const int per_cu = mode == MODE_FLAT ? walk_blocks_per_cu<MODE_FLAT>(stack_levels) : mode == MODE_TREE ? walk_blocks_per_cu<MODE_TREE>(stack_levels)
                                                                                                        : walk_blocks_per_cu<MODE_TREE_UV>(stack_levels);
   const unsigned resident = (unsigned)n_cus * (unsigned)per_cu;
-  // overflow levels of the traversal stacks: the LDS part holds stack_levels entries, a walk parks at most seven siblings per level
-  const int stack_need = 7 * sc.walk_levels + 1;
-  int* spill = nullptr;
-  if (sc.n_nodes8 > 0 && stack_need > stack_levels) {
-    if (!pool.spill.ensure((size_t)resident * kBlock * (size_t)(stack_need - stack_levels) * sizeof(int))) { err = "pool allocation"; return RTX_ERR_OUT_OF_MEMORY; }
-    spill = (int*)pool.spill.ptr;
-  }
 
   auto run = [&](int step, int qa, int qb, unsigned grid) {
-    if (mode == MODE_FLAT) launch_iteration_kernels<MODE_FLAT>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill, pool);
-    else if (mode == MODE_TREE) launch_iteration_kernels<MODE_TREE>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill, pool);
-    else launch_iteration_kernels<MODE_TREE_UV>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, spill, pool);
+    if (mode == MODE_FLAT) launch_iteration_kernels<MODE_FLAT>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, pool);
+    else if (mode == MODE_TREE) launch_iteration_kernels<MODE_TREE>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, pool);
+    else launch_iteration_kernels<MODE_TREE_UV>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, pool);
     ++launches;
   };
   if (hipMemsetAsync(ctl, 0, sizeof(WfControl), stream) != hipSuccess) { err = "memset"; return RTX_ERR_HIP; }
@@ -513,8 +602,8 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
     unsigned long long h[8];
     hipStreamSynchronize(stream);
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_walk_stats), sizeof h);
-    fprintf(stderr, "walk stats (extend): wave trips %llu, inner phases %llu with %.1f lanes, leaf phases %llu with %.1f lanes\n", h[0], h[1], (double)h[2] / (h[1] ? h[1] : 1),
-            h[3], (double)h[4] / (h[3] ? h[3] : 1));
+    fprintf(stderr, "walk stats (extend): wave trips %llu, inner phases %llu with %.1f lanes, leaf phases %llu with %.1f lanes, refills %llu storing %.1f results\n", h[0], h[1],
+            (double)h[2] / (h[1] ? h[1] : 1), h[3], (double)h[4] / (h[3] ? h[3] : 1), h[5], (double)h[6] / (h[5] ? h[5] : 1));
   }
 #endif
   return RTX_OK;

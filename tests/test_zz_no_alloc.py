@@ -66,7 +66,7 @@ def test_noalloc_render_walks_a_shallow_tree_and_refuses_a_deep_one(pkg, load_sc
     W, H = 80, 45
     with pkg.renderer.HipPathTracer(0) as pt:
         pt.upload_scene(sd)
-        assert 7 * pt.bvh_info().wide_levels + 1 <= 48
+        assert 3 * (pt.bvh_info().wide_levels + 1) <= 48
         pt.set_camera(sd.camera(W, H))
         pt.set_settings(sd.settings(width=W, height=H, samples_per_pixel=6, max_depth=10, seed=11, pipeline=abi.PIPELINE_FUSED))
         a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
