@@ -177,6 +177,22 @@ int rtx_selftest(int device_id);
 int rtx_create(rtx_ctx** out_ctx, int device_id);
 int rtx_destroy(rtx_ctx* ctx);
 
+/* One context over several GPUs of the node, for a single-process host such as the reference's C++ caller, whose GPU branch
+ * (engine/main.cpp:362-435) constructs one GPUPathTracer and so drives one GPU however many the machine has.  The context
+ * behaves like a single-device one: rtx_upload_scene builds the reference-order tree once on the host and gives every device its
+ * own copy of the scene (each over its own host link, in parallel); rtx_set_camera applies to all; rtx_render and
+ * rtx_render_device deal the rows of the film (or of the caller's shard) to the devices in turn (rtx_multi_shard), render them
+ * side by side, and gather them into the caller's buffer, which for rtx_render_device is memory of device_ids[0].  The film
+ * equals the single-device film bit for bit.  rtx_trace_closest*, rtx_postprocess* and rtx_get_bvh_info run on device_ids[0];
+ * rtx_render_device_noalloc is refused.  A device may be listed more than once (it then holds one scene copy and renders one
+ * share per listing): that is meant for testing the path on a machine with fewer GPUs.  rtx_destroy frees all of it. */
+int rtx_create_multi(rtx_ctx** out_ctx, const int* device_ids, int n_devices);
+
+/* The share of device `device_rank` of `n_devices` in a render of shard (shard_index, shard_count), as a shard of its own:
+ * *out_index of *out_count.  Packed row j of the caller's shard belongs to device j % n_devices, and is that device's packed row
+ * j / n_devices. */
+int rtx_multi_shard(int shard_index, int shard_count, int device_rank, int n_devices, int* out_index, int* out_count);
+
 /* Replaces GPUPathTracer::upload_scene (cuda_api.hpp:84-89; cuda_pathtracer.cu:234-318).
  * Copies the description, builds both BVHs (the reference-order binary tree of
  * engine/bvh.hpp:148-218 for validation, and the wide one the integrator traverses) and

@@ -118,6 +118,8 @@ TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 EXPORTS = {
     "rtx_selftest": (C.c_int, [C.c_int]),
     "rtx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "rtx_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]),
+    "rtx_multi_shard": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rtx_destroy": (C.c_int, [C.c_void_p]),
     "rtx_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "rtx_set_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),

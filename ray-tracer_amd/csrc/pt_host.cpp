@@ -314,8 +314,7 @@ void HostScene::release() {
   n_nodes = n_prims = 0;
 }
 
-int HostScene::upload(const rtx_scene_desc& d, std::string& err) {
-  release();
+int prepare_scene(const rtx_scene_desc& d, ScenePrep& out, std::string& err) {
   const size_t lim = 0x7fffffff;
   if (d.n_spheres > lim || d.n_planes > lim || d.n_triangles > lim || d.n_boxes > lim || d.n_materials > lim ||
       d.n_spheres + d.n_triangles + d.n_boxes > lim / 2) { err = "too many primitives"; return RTX_ERR_INVALID_ARGUMENT; }
@@ -340,6 +339,41 @@ int HostScene::upload(const rtx_scene_desc& d, std::string& err) {
   }
   for (size_t i = 0; i < d.n_images; ++i) if (!d.images[i].rgb || d.images[i].width <= 0 || d.images[i].height <= 0) { err = "bad image"; return RTX_ERR_INVALID_ARGUMENT; }
 
+  const bool timing = getenv("RTX_TIMING") != nullptr;   // diagnostics: phase times on stderr
+  const auto t0 = std::chrono::steady_clock::now();
+  out.bvh.build(d);
+  const HostBvh& bvh = out.bvh;
+  out.emissive.clear();   // ref: engine/scene.hpp:222-230
+  for (size_t i = 0; i < d.n_spheres; ++i) {
+    const rtx_material& m = d.materials[d.spheres[i].material_id];
+    if (m.emission[0] > 0.0 || m.emission[1] > 0.0 || m.emission[2] > 0.0) out.emissive.push_back((int32_t)i);
+  }
+  out.rank.clear(); out.dead.clear();
+  if (bvh.prims.size() > (size_t)kLinearMaxPrims) {
+    // What the GPU-built tree takes from the reference-order tree: every primitive's position in the reference's leaf order (ties
+    // in t go to the later one), and which primitives the reference can never hit (its slab test rejects a box that is flat along
+    // an axis, ref: engine/bvh.hpp:43, so the primitives of such a leaf are unreachable there).
+    const size_t np = bvh.prims.size(), ns = d.n_spheres, nt = d.n_triangles;
+    auto number = [&](const DPrimRef& p) -> size_t { return p.type == PRIM_SPHERE ? (size_t)p.index : p.type == PRIM_TRIANGLE ? ns + (size_t)p.index : ns + nt + (size_t)p.index; };
+    out.rank.resize(np);
+    parallel_for(np, [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) out.rank[number(bvh.prims[i])] = (int32_t)i; });
+    std::mutex mu;
+    parallel_for(bvh.nodes.size(), [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        const DNodeRef& n = bvh.nodes[i];
+        if (n.count <= 0 || (n.lo[0] != n.hi[0] && n.lo[1] != n.hi[1] && n.lo[2] != n.hi[2])) continue;
+        std::lock_guard<std::mutex> g(mu);
+        if (out.dead.empty()) out.dead.assign(np, 0);
+        for (int k = 0; k < n.count; ++k) out.dead[number(bvh.prims[(size_t)n.first + k])] = 1;
+      }
+    });
+  }
+  if (timing) fprintf(stderr, "[rtx upload] %-28s %8.1f ms\n", "validate, reference tree", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  return RTX_OK;
+}
+
+int HostScene::upload(const rtx_scene_desc& d, const ScenePrep& prep, std::string& err) {
+  release();
   const bool timing = getenv("RTX_TIMING") != nullptr;   // diagnostics: phase times of the upload on stderr
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -348,19 +382,11 @@ int HostScene::upload(const rtx_scene_desc& d, std::string& err) {
     fprintf(stderr, "[rtx upload] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
     t_prev = t;
   };
-  lap("validate");
-  HostBvh bvh;
-  bvh.build(d);
-  lap("bvh build");
+  const HostBvh& bvh = prep.bvh;
   build_seconds = bvh.seconds;
   n_nodes = (int)bvh.nodes.size(); n_prims = (int)bvh.prims.size();
 
-  std::vector<int32_t> emissive;   // ref: engine/scene.hpp:222-230
-  for (size_t i = 0; i < d.n_spheres; ++i) {
-    const rtx_material& m = d.materials[d.spheres[i].material_id];
-    if (m.emission[0] > 0.0 || m.emission[1] > 0.0 || m.emission[2] > 0.0) emissive.push_back((int32_t)i);
-  }
-
+  const std::vector<int32_t>& emissive = prep.emissive;
   bool ok = true;
   std::vector<DImage> imgs(d.n_images);
   for (size_t i = 0; i < d.n_images; ++i) {
@@ -389,26 +415,8 @@ int HostScene::upload(const rtx_scene_desc& d, std::string& err) {
   lap("single-precision scene");
   dev_ref.nodes = d_nodes_ref; dev_ref.prims = d_prims; dev_ref.n_nodes = n_nodes; dev_ref.n_prims = n_prims;
   if (ok && bvh.prims.size() > (size_t)kLinearMaxPrims) {
-    // What the GPU-built tree takes from the reference-order tree: every primitive's position in the reference's leaf order (ties
-    // in t go to the later one), and which primitives the reference can never hit (its slab test rejects a box that is flat along
-    // an axis, ref: engine/bvh.hpp:43, so the primitives of such a leaf are unreachable there).
-    const size_t np = bvh.prims.size(), ns = d.n_spheres, nt = d.n_triangles;
-    auto number = [&](const DPrimRef& p) -> size_t { return p.type == PRIM_SPHERE ? (size_t)p.index : p.type == PRIM_TRIANGLE ? ns + (size_t)p.index : ns + nt + (size_t)p.index; };
-    Staging<int32_t> rank(np);
-    parallel_for(np, [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) rank[number(bvh.prims[i])] = (int32_t)i; });
-    std::vector<uint8_t> dead;
-    std::mutex mu;
-    parallel_for(bvh.nodes.size(), [&](size_t b, size_t e) {
-      for (size_t i = b; i < e; ++i) {
-        const DNodeRef& n = bvh.nodes[i];
-        if (n.count <= 0 || (n.lo[0] != n.hi[0] && n.lo[1] != n.hi[1] && n.lo[2] != n.hi[2])) continue;
-        std::lock_guard<std::mutex> g(mu);
-        if (dead.empty()) dead.assign(np, 0);
-        for (int k = 0; k < n.count; ++k) dead[number(bvh.prims[(size_t)n.first + k])] = 1;
-      }
-    });
-    dev_f.rank = push(pool, rank, ok);
-    const uint8_t* d_dead = dead.empty() ? nullptr : push(pool, dead, ok);
+    dev_f.rank = push(pool, prep.rank, ok);
+    const uint8_t* d_dead = prep.dead.empty() ? nullptr : push(pool, prep.dead, ok);
     lap("ranks and unreachable primitives");
     if (ok) {
       std::string berr;

@@ -53,6 +53,16 @@ struct WideTree {
 // bounded primitive (numbered spheres, triangles, boxes), non-zero = the reference can never hit it (built in as unhittable).
 int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& out, std::string& err);
 
+// What an upload derives from the description on the host alone: computed once, shared by every device that receives the scene.
+struct ScenePrep {
+  HostBvh bvh;
+  Staging<int32_t> rank;        // per bounded primitive (numbered spheres, triangles, boxes): its position in the reference's leaf order
+  std::vector<uint8_t> dead;    // per bounded primitive: non-zero = the reference can never hit it; empty when there is none
+  std::vector<int32_t> emissive;
+};
+// Validates the description and fills `out`; RTX_OK or an error code with `err` set.
+int prepare_scene(const rtx_scene_desc& d, ScenePrep& out, std::string& err);
+
 struct HostScene {
   DScene<float> dev_f;
   DScene<double> dev_d;
@@ -63,7 +73,13 @@ struct HostScene {
   std::vector<DeviceBuffer> pool;   // owns every other device allocation of the scene
   std::vector<rtx_sphere> h_spheres;   // host copies the PathPhoton photon pass is planned from
   std::vector<rtx_material> h_materials;
-  int upload(const rtx_scene_desc& d, std::string& err);
+  // Copies the scene to the current device and builds the eight-wide tree there; `prep` = prepare_scene(d).
+  int upload(const rtx_scene_desc& d, const ScenePrep& prep, std::string& err);
+  int upload(const rtx_scene_desc& d, std::string& err) {
+    ScenePrep prep;
+    const int rc = prepare_scene(d, prep, err);
+    return rc != RTX_OK ? rc : upload(d, prep, err);
+  }
   // Which intersection mode the integrator kernels use for this scene.
   int fused_mode(bool f64) const {
     if (const char* e = getenv("RTX_FORCE_MODE")) { int m = atoi(e); if (m == MODE_TREE || m == MODE_TREE_UV) return m; }   // diagnostics only

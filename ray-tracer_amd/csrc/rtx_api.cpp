@@ -96,6 +96,11 @@ struct rtx_ctx {
   DeviceBuffer partial, film, counters, rays, hits, post_in, post_out, bdpt_store;
   DeviceBuffer ph_lights, ph_targets, ph_out, ph_nodes, ph_data, ph_boxes;   // PathPhoton: photon pass plan, its raw output, the kd-tree
   WavefrontPool wf;         // wavefront-pipeline queues, allocated on first use
+  // Multi-device context (rtx_create_multi): this is the context of the first listed device; `peers` are the contexts of the
+  // others (owned), `gather` holds the peers' rows on this device until they are interleaved into the caller's film.
+  bool multi = false;
+  std::vector<rtx_ctx*> peers;
+  DeviceBuffer gather;
 };
 
 // Words of LDS per lane the traversal stack of a launch needs (0: the scene is tested linearly): the double-precision kernels
@@ -267,9 +272,54 @@ static int create_impl(rtx_ctx** out_ctx, int device_id) {
 }
 int rtx_create(rtx_ctx** out_ctx, int device_id) { return guarded([&] { return create_impl(out_ctx, device_id); }); }
 
+int rtx_create_multi(rtx_ctx** out_ctx, const int* device_ids, int n_devices) {
+  if (!out_ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  if (!device_ids || n_devices < 1 || n_devices > kMaxDevices) return fail(RTX_ERR_INVALID_ARGUMENT, "device list: %d entries (1 to %d)", n_devices, kMaxDevices);
+  return guarded([&] {
+    rtx_ctx* first = nullptr;
+    int rc = create_impl(&first, device_ids[0]);
+    if (rc != RTX_OK) return rc;
+    first->multi = true;
+    for (int k = 1; k < n_devices; ++k) {
+      rtx_ctx* p = nullptr;
+      rc = create_impl(&p, device_ids[k]);
+      if (rc != RTX_OK) { const std::string msg = g_error; (void)rtx_destroy(first); g_error = msg; return rc; }
+      first->peers.push_back(p);
+      // direct access lets the gather copy run device to device over the links between the GPUs; without it the runtime stages
+      // the same copy through the host, so a refusal is not an error
+      if (p->device != first->device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, first->device, p->device) == hipSuccess && can) {
+          (void)hipSetDevice(first->device);
+          const hipError_t e = hipDeviceEnablePeerAccess(p->device, 0);
+          if (e != hipSuccess) (void)hipGetLastError();   // already enabled, or refused: clear the sticky code
+        }
+      }
+    }
+    (void)hipSetDevice(first->device);
+    *out_ctx = first;
+    return (int)RTX_OK;
+  });
+}
+
+int rtx_multi_shard(int shard_index, int shard_count, int device_rank, int n_devices, int* out_index, int* out_count) {
+  if (shard_count < 1) shard_count = 1;
+  if (!out_index || !out_count || shard_index < 0 || shard_index >= shard_count || n_devices < 1 || device_rank < 0 || device_rank >= n_devices)
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_multi_shard(%d, %d, %d, %d)", shard_index, shard_count, device_rank, n_devices);
+  if ((long long)shard_count * n_devices > 0x7fffffffLL) return fail(RTX_ERR_INVALID_ARGUMENT, "shard_count * n_devices overflows");
+  // row y of the caller's shard: y = shard_index + shard_count * j; device k takes the j with j % n_devices == k
+  *out_index = shard_index + shard_count * device_rank;
+  *out_count = shard_count * n_devices;
+  return RTX_OK;
+}
+
 int rtx_destroy(rtx_ctx* c) {
   if (!c) return RTX_OK;
+  for (rtx_ctx* p : c->peers) (void)rtx_destroy(p);
+  c->peers.clear();
   (void)hipSetDevice(c->device);
+  c->gather.release();
   (void)hipStreamSynchronize(c->stream);
   c->scene.release();
   c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release(); c->post_in.release(); c->post_out.release(); c->bdpt_store.release();
@@ -285,16 +335,38 @@ int rtx_destroy(rtx_ctx* c) {
 
 static int upload_impl(rtx_ctx* c, const rtx_scene_desc* d) {
   if (!c || !d) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
-  HIP_TRY(hipSetDevice(c->device));
+  c->has_scene = false;
+  for (rtx_ctx* p : c->peers) p->has_scene = false;
   std::string err;
-  int rc = c->scene.upload(*d, err);
-  if (rc != RTX_OK) { c->has_scene = false; return fail(rc, "upload_scene: %s", err.c_str()); }
-  c->has_scene = true;
+  ScenePrep prep;   // the reference-order tree and what derives from it: built once, whatever the number of devices
+  int rc = prepare_scene(*d, prep, err);
+  if (rc != RTX_OK) return fail(rc, "upload_scene: %s", err.c_str());
+  // every device takes its copy over its own host link and builds its eight-wide tree itself (the build is deterministic,
+  // so the trees are identical): one host thread per device
+  std::vector<rtx_ctx*> all{c};
+  all.insert(all.end(), c->peers.begin(), c->peers.end());
+  std::vector<int> rcs(all.size(), RTX_OK);
+  std::vector<std::string> errs(all.size());
+  auto one = [&](size_t k) {
+    try {
+      if (hipSetDevice(all[k]->device) != hipSuccess) { rcs[k] = RTX_ERR_HIP; errs[k] = "hipSetDevice failed"; return; }
+      rcs[k] = all[k]->scene.upload(*d, prep, errs[k]);
+    } catch (const std::bad_alloc&) { rcs[k] = RTX_ERR_OUT_OF_MEMORY; errs[k] = "host allocation failed";
+    } catch (const std::exception& e) { rcs[k] = RTX_ERR_HIP; errs[k] = e.what(); }
+  };
+  std::vector<std::thread> th;
+  for (size_t k = 1; k < all.size(); ++k) th.emplace_back(one, k);
+  one(0);
+  for (std::thread& t : th) t.join();
+  (void)hipSetDevice(c->device);
+  for (size_t k = 0; k < all.size(); ++k)
+    if (rcs[k] != RTX_OK) return fail(rcs[k], "upload_scene (device %d): %s", all[k]->device, errs[k].c_str());
+  for (rtx_ctx* x : all) x->has_scene = true;
   return RTX_OK;
 }
 int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d) {
   const int rc = guarded([&] { return upload_impl(c, d); });
-  if (rc != RTX_OK && c) c->has_scene = false;
+  if (rc != RTX_OK && c) { c->has_scene = false; for (rtx_ctx* p : c->peers) p->has_scene = false; }
   return rc;
 }
 
@@ -307,6 +379,7 @@ int rtx_set_camera(rtx_ctx* c, const rtx_camera* cam) {
     c->cam_f.horizontal[i] = (float)cam->horizontal[i]; c->cam_f.vertical[i] = (float)cam->vertical[i];
   }
   c->has_camera = true;
+  for (rtx_ctx* p : c->peers) { p->cam_d = c->cam_d; p->cam_f = c->cam_f; p->has_camera = true; }
   return RTX_OK;
 }
 
@@ -502,18 +575,104 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   return RTX_OK;
 }
 
+// Render of a multi-device context.  The caller's shard (rows y with y % shard_count == shard_index, packed bottom-up: packed
+// row j is y = shard_index + shard_count * j) is dealt to the devices row by row: device k renders the packed rows j with
+// j % n == k, which is shard rtx_multi_shard(k) of the film, with the kernels and sample streams of a single-device render, so the
+// gathered film equals the single-device film bit for bit.  Each device renders on a host thread of its own into its own buffer;
+// the rows then go to the caller's film interleaved: to host memory by one strided copy per device (every device over its own
+// host link), to device memory by a copy to the first device followed by a strided copy there.
+static int render_multi(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, rtx_stats* stats) {
+  if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (s->width <= 0 || s->height <= 0) return fail(RTX_ERR_INVALID_ARGUMENT, "bad settings: %dx%d", s->width, s->height);
+  const auto wall0 = std::chrono::steady_clock::now();
+  std::vector<rtx_ctx*> all{c};
+  all.insert(all.end(), c->peers.begin(), c->peers.end());
+  const int n = (int)all.size();
+  const size_t row_bytes = (size_t)s->width * 3 * sizeof(float);
+  std::vector<rtx_settings> sk(n, *s);
+  std::vector<int> rows(n, 0);
+  for (int k = 0; k < n; ++k) {
+    const int rc = rtx_multi_shard(s->shard_index, s->shard_count, k, n, &sk[k].shard_index, &sk[k].shard_count);
+    if (rc != RTX_OK) return rc;
+    rows[k] = rtx_shard_rows(s->height, sk[k].shard_index, sk[k].shard_count);
+  }
+  std::vector<int> rcs(n, RTX_OK);
+  std::vector<std::string> errs(n);
+  std::vector<rtx_stats> sts(n);
+  auto one = [&](int k) {
+    rtx_ctx* x = all[k];
+    memset(&sts[k], 0, sizeof(rtx_stats));
+    if (rows[k] == 0) return;
+    try {
+      if (hipSetDevice(x->device) != hipSuccess) { rcs[k] = RTX_ERR_HIP; errs[k] = "hipSetDevice failed"; return; }
+      if (!x->film.ensure((size_t)rows[k] * row_bytes)) { rcs[k] = RTX_ERR_OUT_OF_MEMORY; errs[k] = "film buffer"; return; }
+      rcs[k] = render_impl(x, &sk[k], nullptr, x->film.ptr, nullptr, &sts[k]);   // returns with the device's rows complete
+      if (rcs[k] != RTX_OK) { errs[k] = g_error; return; }
+      if (host_out) {
+        const hipError_t e = hipMemcpy2D((char*)host_out + (size_t)k * row_bytes, (size_t)n * row_bytes, x->film.ptr, row_bytes, row_bytes, (size_t)rows[k], hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rcs[k] = RTX_ERR_HIP; errs[k] = std::string("film copy to the host: ") + hipGetErrorString(e); }
+      }
+    } catch (const std::bad_alloc&) { rcs[k] = RTX_ERR_OUT_OF_MEMORY; errs[k] = "host allocation failed";
+    } catch (const std::exception& e) { rcs[k] = RTX_ERR_HIP; errs[k] = e.what(); }
+  };
+  std::vector<std::thread> th;
+  for (int k = 1; k < n; ++k) th.emplace_back(one, k);
+  one(0);
+  for (std::thread& t : th) t.join();
+  HIP_TRY(hipSetDevice(c->device));
+  for (int k = 0; k < n; ++k)
+    if (rcs[k] != RTX_OK) return fail(rcs[k], "render (device %d, shard %d of %d): %s", all[k]->device, sk[k].shard_index, sk[k].shard_count, errs[k].c_str());
+  if (dev_out) {
+    hipStream_t stream = user_stream ? user_stream : c->stream;
+    size_t peer_bytes = 0;
+    for (int k = 1; k < n; ++k) peer_bytes += (size_t)rows[k] * row_bytes;
+    if (peer_bytes && !c->gather.ensure(peer_bytes)) return fail(RTX_ERR_OUT_OF_MEMORY, "gather buffer (%zu bytes)", peer_bytes);
+    size_t at = 0;
+    for (int k = 0; k < n; ++k) {
+      if (rows[k] == 0) continue;
+      const void* src = all[k]->film.ptr;
+      if (k > 0) {
+        void* stage = (char*)c->gather.ptr + at;
+        at += (size_t)rows[k] * row_bytes;
+        HIP_TRY(hipMemcpyPeerAsync(stage, c->device, src, all[k]->device, (size_t)rows[k] * row_bytes, stream));
+        src = stage;
+      }
+      HIP_TRY(hipMemcpy2DAsync((char*)dev_out + (size_t)k * row_bytes, (size_t)n * row_bytes, src, row_bytes, row_bytes, (size_t)rows[k], hipMemcpyDeviceToDevice, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
+  if (stats) {
+    rtx_stats t = sts[0];
+    for (int k = 1; k < n; ++k) {
+      const rtx_stats& a = sts[k];
+      t.samples += a.samples; t.rays_closest += a.rays_closest; t.rays_shadow += a.rays_shadow; t.segments += a.segments;
+      t.nodes_visited += a.nodes_visited; t.prims_tested += a.prims_tested; t.kernel_launches += a.kernel_launches;
+      // the devices run side by side: the call takes as long as the slowest
+      t.seconds_render = std::max(t.seconds_render, a.seconds_render); t.seconds_main_kernel = std::max(t.seconds_main_kernel, a.seconds_main_kernel);
+      t.seconds_photon_pass = std::max(t.seconds_photon_pass, a.seconds_photon_pass); t.seconds_extend = std::max(t.seconds_extend, a.seconds_extend);
+      if (t.pipeline_used == 0) { t.pipeline_used = a.pipeline_used; t.precision_used = a.precision_used; }
+    }
+    t.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+    *stats = t;
+  }
+  return RTX_OK;
+}
+
 int rtx_render(rtx_ctx* c, const rtx_settings* s, float* out_rgb, rtx_stats* stats) {
   if (!out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "out_rgb is NULL");
+  if (c && c->multi) return guarded([&] { return render_multi(c, s, out_rgb, nullptr, nullptr, stats); });
   return guarded([&] { return render_impl(c, s, out_rgb, nullptr, nullptr, stats); });
 }
 
 int rtx_render_device_noalloc(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* hip_stream, rtx_stats* stats) {
   if (!d_out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "d_out_rgb is NULL");
+  if (c && c->multi) return fail(RTX_ERR_UNSUPPORTED, "the no-allocation render takes a single-device context (rtx_create)");
   return guarded([&] { return render_impl(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, stats, true); });
 }
 
 int rtx_render_device(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* hip_stream, rtx_stats* stats) {
   if (!d_out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "d_out_rgb is NULL");
+  if (c && c->multi) return guarded([&] { return render_multi(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, stats); });
   return guarded([&] { return render_impl(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, stats); });
 }
 

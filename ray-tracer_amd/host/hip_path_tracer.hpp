@@ -8,6 +8,7 @@
 #pragma once
 
 #include <cstdio>
+#include <vector>
 
 #include "../../include/rtx_hip.h"
 
@@ -24,6 +25,8 @@ inline bool test_hip(int device_id = 0) {
 class HipPathTracer {
  public:
   explicit HipPathTracer(int device_id = 0) { note(rtx_create(&ctx_, device_id), "rtx_create"); }
+  // One tracer over several GPUs of the node (rtx_create_multi): the same calls, the film's rows dealt to the devices and gathered.
+  explicit HipPathTracer(const std::vector<int>& device_ids) { note(rtx_create_multi(&ctx_, device_ids.data(), (int)device_ids.size()), "rtx_create_multi"); }
   ~HipPathTracer() { if (ctx_) rtx_destroy(ctx_); }
   HipPathTracer(const HipPathTracer&) = delete;
   HipPathTracer& operator=(const HipPathTracer&) = delete;

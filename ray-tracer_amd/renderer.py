@@ -23,10 +23,16 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("prim_type", "<i4"), ("prim_index", "<i4"
 
 
 class HipPathTracer:
-    def __init__(self, device_id: int = 0):
+    def __init__(self, device_id: int = 0, device_ids: list[int] | None = None):
+        """One GPU (`device_id`, as GPUPathTracer), or with `device_ids` one context over several GPUs of the node
+        (rtx_create_multi): same methods, the rows of the film dealt to the devices and gathered on device_ids[0]."""
         self._lib = abi.load_library()
         self._ctx = C.c_void_p()
-        abi.check(self._lib, self._lib.rtx_create(C.byref(self._ctx), device_id), "rtx_create")
+        if device_ids is None:
+            abi.check(self._lib, self._lib.rtx_create(C.byref(self._ctx), device_id), "rtx_create")
+        else:
+            ids = (C.c_int * len(device_ids))(*device_ids)
+            abi.check(self._lib, self._lib.rtx_create_multi(C.byref(self._ctx), ids, len(device_ids)), "rtx_create_multi")
         self._settings: abi.Settings | None = None
         self._scene_keepalive = None
         self.last_stats: abi.Stats | None = None
