@@ -985,6 +985,13 @@ RTX_DEV bool flat_plane_t(const float* p, const float* n, const Ray<float>& r, f
   t = num * rcp_(denom);
   return fabsf(denom) >= 1e-8f && t >= t_min && t <= t_max;
 }
+// The same test for a plane whose constant pd = n . p was computed at upload: t = (pd - n . o) / (n . d).
+RTX_DEV bool flat_plane_pd(const float* n, float pd, const Ray<float>& r, float t_min, float t_max, float& t) {
+  float denom = n[0] * r.d.x + n[1] * r.d.y + n[2] * r.d.z;
+  float num = pd - (n[0] * r.o.x + n[1] * r.o.y + n[2] * r.o.z);
+  t = num * rcp_(denom);
+  return fabsf(denom) >= 1e-8f && t >= t_min && t <= t_max;
+}
 // ref: engine/primitives.hpp:274-300
 RTX_DEV bool flat_quad_t(const DQuad<float>& q, const Ray<float>& r, float t_min, float t_max, float& t) {
   bool ok = flat_plane_t(q.corner, q.n, r, t_min, t_max, t);
@@ -1012,7 +1019,7 @@ RTX_DEV bool flat_closest(const DScene<float>& sc, const Ray<float>& r, float t_
     best = ok ? t : best; k = ok ? n : k;
   }
   for (int i = 0; i < sc.n_planes; ++i, ++n) {
-    const bool ok = flat_plane_t(sc.planes[i].p, sc.planes[i].n, r, t_min, best, t);
+    const bool ok = flat_plane_pd(sc.planes[i].n, sc.planes[i].pd, r, t_min, best, t);
     best = ok ? t : best; k = ok ? n : k;
   }
   for (int i = 0; i < sc.n_quads; ++i, ++n) {
@@ -1033,12 +1040,13 @@ RTX_DEV bool flat_closest(const DScene<float>& sc, const Ray<float>& r, float t_
   return true;
 }
 
-RTX_DEV bool flat_occluded(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_max) {
-  const float a = len2(r.d), inv_a = rcp_(a);
+// UNIT: the caller's direction has unit length (the light-sample rays of the path tracer), so |d|^2 is taken as 1.
+template <bool UNIT = false> RTX_DEV bool flat_occluded(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_max) {
+  const float a = UNIT ? 1.f : len2(r.d), inv_a = UNIT ? 1.f : rcp_(a);
   float t;
   bool any = false;
   for (int i = 0; i < sc.n_prims; ++i) any |= flat_sphere_t(sc.spheres[sc.prims[i].index], r, a, inv_a, t_min, t_max, t);
-  for (int i = 0; i < sc.n_planes; ++i) any |= flat_plane_t(sc.planes[i].p, sc.planes[i].n, r, t_min, t_max, t);
+  for (int i = 0; i < sc.n_planes; ++i) any |= flat_plane_pd(sc.planes[i].n, sc.planes[i].pd, r, t_min, t_max, t);
   for (int i = 0; i < sc.n_quads; ++i) any |= flat_quad_t(sc.quads[i], r, t_min, t_max, t);
   for (int i = 0; i < sc.n_disks; ++i) any |= flat_disk_t(sc.disks[i], r, t_min, t_max, t);
   return any;
@@ -1051,8 +1059,8 @@ template <class R, int MODE> RTX_DEV bool trace_closest(const DScene<R>& sc, con
   else if constexpr (MODE == MODE_TREE_UV) return closest_hit<R, true>(sc, r, t_min, t_max, h, st);
   else return closest_hit<R, false>(sc, r, t_min, t_max, h, st);
 }
-template <class R, int MODE> RTX_DEV bool trace_occluded(const DScene<R>& sc, const Ray<R>& r, R t_min, R t_max, LaneStack st) {
-  if constexpr (MODE == MODE_FLAT) return flat_occluded(sc, r, t_min, t_max);
+template <class R, int MODE, bool UNIT = false> RTX_DEV bool trace_occluded(const DScene<R>& sc, const Ray<R>& r, R t_min, R t_max, LaneStack st) {
+  if constexpr (MODE == MODE_FLAT) return flat_occluded<UNIT>(sc, r, t_min, t_max);
   else return occluded(sc, r, t_min, t_max, st);
 }
 
@@ -1342,7 +1350,7 @@ RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMateria
     return path_vertex_impl<R, INTEG == INTEG_PATH_MNEE, NMAP>(
         ps, hit, rec, sc, mats, P, key,
         [&](const Ray<R>& sr, R t_max, V3<R> contrib) {
-          const bool visible = !trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st);
+          const bool visible = !trace_occluded<R, MODE, true>(sc, sr, R(0.001), t_max, st);   // light-sample rays are normalised
           if (visible) ps.acc = ps.acc + contrib;
           return visible;
         },

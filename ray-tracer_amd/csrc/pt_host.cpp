@@ -184,7 +184,9 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
   std::vector<DSphere<R>> sph(d.n_spheres);
   for (size_t i = 0; i < d.n_spheres; ++i) { cp3(sph[i].c, d.spheres[i].center); sph[i].radius = (R)d.spheres[i].radius; sph[i].mat = d.spheres[i].material_id; sph[i].pad = 0; }
   std::vector<DPlane<R>> pls(d.n_planes);
-  for (size_t i = 0; i < d.n_planes; ++i) { cp3(pls[i].p, d.planes[i].point); cp3(pls[i].n, d.planes[i].normal); pls[i].mat = d.planes[i].material_id; pls[i].pad = 0; }
+  for (size_t i = 0; i < d.n_planes; ++i) { cp3(pls[i].p, d.planes[i].point); cp3(pls[i].n, d.planes[i].normal); pls[i].mat = d.planes[i].material_id;
+    pls[i].pd = (float)(d.planes[i].normal[0] * d.planes[i].point[0] + d.planes[i].normal[1] * d.planes[i].point[1] + d.planes[i].normal[2] * d.planes[i].point[2]);
+  }
   // rtx_triangle and DTri<double> have the same layout: the double-precision scene takes the caller's array as it is
   static_assert(sizeof(DTri<double>) == sizeof(rtx_triangle) && offsetof(DTri<double>, mat) == offsetof(rtx_triangle, material_id), "layout");
   Staging<DTri<R>> tris;

@@ -10,7 +10,7 @@
 namespace rtx {
 
 template <class R> struct DSphere { R c[3]; R radius; int32_t mat; int32_t pad; };
-template <class R> struct DPlane { R p[3]; R n[3]; int32_t mat; int32_t pad; };
+template <class R> struct DPlane { R p[3]; R n[3]; int32_t mat; float pd; };   // pd = n . p, read by the flat single-precision test
 template <class R> struct DTri { R v0[3], v1[3], v2[3]; int32_t mat; int32_t pad; };
 template <class R> struct DBox { R lo[3], hi[3]; int32_t mat; int32_t pad; };
 template <class R> struct DPoint { R pos[3], I[3]; };

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays 
       if (__ballot(state == 1 || have_next) == 0ull) break;
     }
     if constexpr (MODE == MODE_FLAT) {
-      if (state == 1) state = flat_occluded(sc, sr, 0.001f, t_max) ? 2 : 3;
+      if (state == 1) state = flat_occluded<true>(sc, sr, 0.001f, t_max) ? 2 : 3;   // queued light-sample rays are normalised
     } else if (!tree) {
       if (state == 1) state = occluded(sc, sr, 0.001f, t_max, st) ? 2 : 3;
     } else {
