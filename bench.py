@@ -27,9 +27,13 @@ sys.path.insert(0, ROOT)
 SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E peak (spec)
-# Vector-ALU issue ceiling: 256 CUs x 4 SIMDs, one wave64 instruction per SIMD every VALU_CYCLES_PER_INST cycles at 2.4 GHz
-# (measured with scripts/valu_peak.hip: profiles/r02_valu_peak.jsonl).
-N_SIMDS, CLOCK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 4.0
+# Vector-ALU issue ceiling: 256 CUs x 4 SIMDs at 2.4 GHz.  A SIMD takes four cycles per wave64 instruction and can issue two
+# such instructions (of different waves) in one four-cycle slot: the hardware counts those slots (SQ_ACTIVE_INST_VALU2), and a
+# stream of v_mov_b32 runs at 2.6 cycles per instruction (scripts/valu_peak.hip, profiles/r02_valu_peak.jsonl).  The ceiling is
+# therefore two instructions per SIMD per four cycles; streams of one full-rate arithmetic opcode sustain 0.44 of it (v_fma_f32:
+# 543 Gwave-inst/s, clocks included), v_rcp/v_sqrt/v_sin half of that.
+N_SIMDS, CLOCK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 2.0
+VALU_STREAM_RATES = {"v_fma_f32": 542.9, "v_mov_b32": 955.6, "v_rcp_f32": 299.6}   # Gwave-inst/s at 8 waves per SIMD, launches of >= 100 ms
 # What a queue-based path tracer would move per unit of work (path state written + read 96 B + hit record 32 B + two queue
 # indices 16 B per path segment; 88 B per shadow ray; 24 B of film accumulation per sample): reported as an equivalent
 # rate only; the fused kernel keeps that state in registers.
@@ -197,8 +201,11 @@ def roofline(args, abi, jobs, stats, world):
     on the launch stream, rtx_stats.seconds_main_kernel).  The instruction count is a property of (kernel binary, workload):
     every lane's work items are fixed by its index, so it is taken from the committed rocprofv3 --pmc profile of this very
     workload - and only if that profile names the shared library that has just been timed (SHA-256), else it is null.
-    Queue pipeline (c5): the traversal kernel is bound by incoherent line fetches: achieved = (node records visited x record
-    bytes + primitives tested x primitive bytes, both counted live by the kernel) / its time measured live."""
+    Queue pipeline (c5): the traversal kernel is bound by incoherent record fetches from HBM.  The kernel counts live the node
+    and leaf records it fetches; that figure x record bytes / its live time is the rate at which it consumes records
+    (`record_fetch_GBps`), of which the caches serve the top of the tree.  `achieved` is what HBM itself delivered: the
+    FETCH_SIZE + WRITE_SIZE bytes of the kernel's launches in the committed profile of this library build and workload / the
+    live time (null when no such profile exists), so that frac is a share of the HBM peak."""
     first = [s for i, s in enumerate(stats) if i % len(jobs) == 0]   # scene 0 of every step
     n = len(first)
     seg = sum(s.segments for s in first) / n
@@ -221,10 +228,13 @@ def roofline(args, abi, jobs, stats, world):
     if fused:
         peak = N_SIMDS * CLOCK_HZ / VALU_CYCLES_PER_INST / 1e9
         r.update({"bound": "valu", "unit": "Gwave-inst/s", "peak": peak, "kernel": "render_fused_kernel<float>",
-                  "achieved": None, "frac": None, "lanes_active": None, "traffic": None, "hbm_frac": None})
+                  "peak_definition": "two wave64 instructions per SIMD per 4 cycles (dual issue) x 1024 SIMDs x 2.4 GHz",
+                  "single_issue_rate": peak / 2, "measured_stream_rates": VALU_STREAM_RATES,
+                  "achieved": None, "frac": None, "lanes_active": None, "valu_busy": None, "traffic": None, "hbm_frac": None})
         if prof:
             ach = prof["SQ_INSTS_VALU"] / kern_s / 1e9
-            r.update({"achieved": ach, "frac": ach / peak, "lanes_active": prof.get("lanes_active"), "traffic": prof.get("hbm_bytes_per_launch"),
+            r.update({"achieved": ach, "frac": ach / peak, "lanes_active": prof.get("lanes_active"), "valu_busy": prof.get("valu_busy"),
+                      "traffic": prof.get("hbm_bytes_per_launch"),
                       "hbm_frac": (prof["hbm_bytes_per_launch"] / kern_s / 1e9 / HBM_PEAK_GBPS) if prof.get("hbm_bytes_per_launch") else None,
                       "valu_insts_per_segment": prof["SQ_INSTS_VALU"] * 64.0 / seg, "kernel_symbol": prof.get("kernel"),
                       "kernel_ms_rocprof": prof.get("kernel_ms_rocprof")})
@@ -240,11 +250,14 @@ def roofline(args, abi, jobs, stats, world):
                   "kernel_ms": ext_s * 1e3, "frame_ms": kern_s * 1e3, "achieved": None, "frac": None, "traffic": None})
         if ext_s > 0 and nodes > 0:
             alg = nodes * rec_b + prims * info.leaf_bytes
-            r.update({"achieved": alg / ext_s / 1e9, "frac": alg / ext_s / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch_set": alg,
+            r.update({"record_fetch_GBps": alg / ext_s / 1e9, "record_bytes_per_launch_set": alg,
                       "node_records_per_ray": nodes / rays, "leaf_records_per_ray": prims / rays, "node_record_bytes": rec_b, "leaf_record_bytes": info.leaf_bytes,
                       "grays_per_s_closest_hit": rays / ext_s / 1e9})
-        if prof:
-            r.update({"traffic": prof.get("hbm_bytes_per_launch"), "lanes_active": prof.get("lanes_active"), "kernel_ms_rocprof": prof.get("kernel_ms_rocprof")})
+            if prof and prof.get("hbm_bytes_per_launch"):
+                hbm = prof["hbm_bytes_per_launch"]
+                r.update({"achieved": hbm / ext_s / 1e9, "frac": hbm / ext_s / 1e9 / HBM_PEAK_GBPS, "traffic": hbm, "share_of_record_bytes_served_by_caches": 1.0 - hbm / alg,
+                          "lanes_active": prof.get("lanes_active"), "l2_hit_rate": prof.get("l2_hit_rate"), "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"),
+                          "kernel_symbol": prof.get("kernel")})
     return r
 
 

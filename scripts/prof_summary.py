@@ -41,6 +41,10 @@ for k, e in K.items():
     d = {}
     if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
         d["valu_issue_busy_4cyc"] = c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+    if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+        d["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] / 256.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)   # rocprofv3's VALUBusy: above 1 when instructions issue in pairs
+    if "SQ_ACTIVE_INST_VALU2" in c and c.get("SQ_ACTIVE_INST_VALU", 0) > 0:
+        d["valu_dual_issue_share"] = c["SQ_ACTIVE_INST_VALU2"] / c["SQ_ACTIVE_INST_VALU"]
     if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU", 0) > 0:
         d["lanes_active"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
