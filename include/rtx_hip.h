@@ -122,7 +122,8 @@ typedef struct rtx_settings {
   int32_t width, height;
   int32_t samples_per_pixel;
   int32_t max_depth;
-  int32_t use_nee, use_mis, use_mnee;      /* use_mnee (Renderer::Settings::use_mnee, engine/renderer.hpp:101-133): renders in double precision, fused pipeline */
+  int32_t use_nee, use_mis, use_mnee;      /* use_mnee (Renderer::Settings::use_mnee, engine/renderer.hpp:101-133): fused pipeline; with RTX_PRECISION_F32 the closest-hit
+                                            * queries run in single precision and the manifold walk in double, with RTX_PRECISION_F64 everything is the reference's arithmetic */
   int32_t use_background_gradient;
   double background_color[3], background_top[3], background_bottom[3];
   uint32_t seed;
@@ -150,7 +151,7 @@ typedef struct rtx_stats {
   double seconds_total;      /* wall time of the call */
   uint32_t kernel_launches;
   uint32_t pipeline_used;    /* RTX_PIPELINE_FUSED or _WAVEFRONT */
-  uint32_t precision_used;   /* RTX_PRECISION_*: use_mnee promotes a single-precision request to double */
+  uint32_t precision_used;   /* RTX_PRECISION_* the render ran in */
   uint32_t reserved_;
   double seconds_photon_pass;/* PathPhoton: wall time of the photon pass (trace kernel, kd-tree build on the host, uploads); else 0 */
   /* queue-based pipeline only (0 otherwise): the closest-hit traversal kernel of the ray queue */

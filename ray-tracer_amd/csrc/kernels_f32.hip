@@ -59,6 +59,13 @@ int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, cons
     else hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, false, INTEG_WHITTED>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     return 0;
   }
+  if (L.integ == INTEG_PATH_MNEE) {   // manifold NEE: single-precision traces, the manifold walk itself in double (pt_mnee.hpp)
+    if (L.mode == MODE_FLAT && L.lds_mats) hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH_MNEE>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else if (L.mode == MODE_FLAT) return -1;
+    else if (L.lds_mats) hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, true, INTEG_PATH_MNEE>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, false, INTEG_PATH_MNEE>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    return 0;
+  }
   if (L.integ != INTEG_PATH) return -1;
   if (L.mode == MODE_FLAT && L.lds_mats)
   {

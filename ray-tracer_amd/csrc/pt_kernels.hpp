@@ -65,6 +65,9 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #ifndef RTX_PHOTON_FLAT_MIN_WAVES
 #define RTX_PHOTON_FLAT_MIN_WAVES 4   // PathPhoton on a flat scene
 #endif
+#ifndef RTX_MNEE_F32_MIN_WAVES
+#define RTX_MNEE_F32_MIN_WAVES 3   // manifold NEE instances with single-precision traces (measured on the 1080p Cornell box: 1: 50.9 Msamples/s, 2: 75.6, 3: 82.5, 4: 77.1)
+#endif
 #ifndef RTX_MNEE_MIN_WAVES
 #define RTX_MNEE_MIN_WAVES 3   // manifold NEE instance (double precision): measured 1: 330 ms, 2: 240, 3: 219, 4: 263 (cornell_box_quad 800x800x16)
 #endif
@@ -72,7 +75,7 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 // branch on them folds away: 1 = no environment map, 2 = no point and no disk lights, 4 = no quad lights,
 // 8 = NEE and MIS on, 16 = the pcg4d generator, 32 = no material has a normal map (the tangent-frame code is left out).
 template <class R, int MODE, bool LDS_MATS, int INTEG = INTEG_PATH, int LEAN = 0>
-__global__ __launch_bounds__(kBlock, (MODE == MODE_FLAT ? (INTEG == INTEG_PATHPHOTON ? RTX_PHOTON_FLAT_MIN_WAVES : (LEAN & 1) ? RTX_LEAN_MIN_WAVES : (LEAN ? RTX_LEAN_ENV_MIN_WAVES : RTX_FLAT_MIN_WAVES)) : (INTEG == INTEG_PATH_MNEE ? RTX_MNEE_MIN_WAVES : (sizeof(R) == 4 ? (INTEG == INTEG_PATHPHOTON ? RTX_PHOTON_MIN_WAVES : RTX_TREE_MIN_WAVES) : 1)))) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
+__global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4) ? RTX_MNEE_F32_MIN_WAVES : (MODE == MODE_FLAT ? (INTEG == INTEG_PATHPHOTON ? RTX_PHOTON_FLAT_MIN_WAVES : (LEAN & 1) ? RTX_LEAN_MIN_WAVES : (LEAN ? RTX_LEAN_ENV_MIN_WAVES : RTX_FLAT_MIN_WAVES)) : (INTEG == INTEG_PATH_MNEE ? RTX_MNEE_MIN_WAVES : (sizeof(R) == 4 ? (INTEG == INTEG_PATHPHOTON ? RTX_PHOTON_MIN_WAVES : RTX_TREE_MIN_WAVES) : 1)))) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
                                                                DCounters* __restrict__ counters, int stack_first_int) {
   if constexpr ((LEAN & 1) != 0) { sc.env.valid = 0; sc.env.importance = 0; }
   if constexpr ((LEAN & 2) != 0) { sc.n_points = 0; sc.n_disks = 0; }

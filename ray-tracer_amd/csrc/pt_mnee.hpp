@@ -3,9 +3,13 @@
 // engine/renderer.cpp:716-732).  Every routine follows its reference counterpart statement by
 // statement; closest-hit queries go through `trace`, a functor
 //     bool trace(const Ray<R>&, R t_min, R t_max, Hit<R>&)
-// with the semantics of Scene::hit.  Instantiated for double only: the Newton solver's
-// convergence threshold (1e-6 on unit vectors) and finite-difference step (1e-5) leave no
-// room for single precision.
+// with the semantics of Scene::hit.  Two type parameters: S, the type the manifold walk computes in, and R, the type of the
+// scene and of the rays `trace` takes.  S is always double: the Newton solver's convergence threshold (1e-6 on unit
+// vectors) and finite-difference step (1e-5) leave no room for single precision.  With R = double this is the reference's
+// arithmetic (the parity mode).  With R = float the closest-hit queries - nearly all of the work - run in single precision
+// on the production structures, and every point they return on a sphere or a plane is put back onto that surface in double
+// (mnee_surface_point), so that the solver sees a consistent surface: a vertex that is off by single-precision rounding
+// ALONG the surface is still a valid manifold vertex, one that is off ACROSS it is not.
 #pragma once
 
 #include "pt_device.hpp"
@@ -14,6 +18,52 @@ namespace rtx {
 
 template <class R> struct MVertex { V3<R> p, n; R eta; int mat; };   // ManifoldVertex, mnee.hpp:32-39 (members the solver reads)
 constexpr int kMneeMaxIter = 20, kMneeMaxDepth = 4;                  // mnee.hpp:59-60
+
+template <class A, class B> struct mnee_same { static constexpr bool value = false; };
+template <class A> struct mnee_same<A, A> { static constexpr bool value = true; };
+template <class T, class U> RTX_DEV V3<T> v3_to(V3<U> v) { return {T(v.x), T(v.y), T(v.z)}; }
+
+// Closest hit of the S-typed ray (o, d) through the R-typed scene; on a hit, the point and the face-forwarded normal in S
+// (rec.front is set to match).  With R = float the single-precision query only decides WHICH primitive is hit first; for a
+// sphere or a plane the hit itself is then computed again in S from the S-typed ray, with the reference's root choice
+// (engine/sphere.hpp:71-92, engine/primitives.hpp:35-48).  Without that, every reprojection would move its vertex by the
+// rounding of a single-precision origin (4e-7 at these scenes' coordinates), which is the size of the solver's convergence
+// threshold: three quarters of the connections the double-precision walk finds were lost that way.
+template <class S, class R, class Trace> RTX_DEV bool mnee_trace(const DScene<R>& sc, V3<S> o, V3<S> d, S t_min, S t_max, Hit<R>& rec, V3<S>& p, V3<S>& n, Trace& trace) {
+  Ray<R> r = {v3_to<R>(o), v3_to<R>(d)};
+  if (!trace(r, R(t_min), R(t_max), rec)) return false;
+  p = v3_to<S>(rec.p); n = v3_to<S>(rec.n);
+  if constexpr (!mnee_same<S, R>::value) {
+    if (rec.type == PRIM_SPHERE) {
+      const DSphere<R>& sp = sc.spheres[rec.idx];
+      const V3<S> c = {S(sp.c[0]), S(sp.c[1]), S(sp.c[2])};
+      const S rad = S(sp.radius);
+      const V3<S> oc = o - c;
+      const S a = len2(d), hb = dot(oc, d), cc = len2(oc) - rad * rad, disc = hb * hb - a * cc;
+      V3<S> out;
+      if (disc >= S(0)) {
+        // the root in range, near one first; when rounding leaves neither in range (a ray that starts on the sphere), the root
+        // next to the single-precision distance
+        const S sq = sqrt_(disc), t0 = (-hb - sq) / a, t1 = (-hb + sq) / a, tf = S(rec.t);
+        const bool in0 = t0 >= t_min && t0 <= t_max, in1 = t1 >= t_min && t1 <= t_max;
+        const S t = in0 ? t0 : in1 ? t1 : (abs_(t0 - tf) < abs_(t1 - tf) ? t0 : t1);
+        p = o + d * t; out = (p - c) * (S(1) / rad);
+      } else { out = normalize(p - c); p = c + out * rad; }   // a grazing hit the two precisions disagree on: the single-precision point, put onto the sphere
+      rec.front = dot(d, out) < S(0);
+      n = rec.front ? out : -out;
+    } else if (rec.type == PRIM_PLANE) {
+      const DPlane<R>& pl = sc.planes[rec.idx];
+      const V3<S> pn = {S(pl.n[0]), S(pl.n[1]), S(pl.n[2])}, p0 = {S(pl.p[0]), S(pl.p[1]), S(pl.p[2])};
+      const S denom = dot(pn, d);
+      const S t = dot(p0 - o, pn) / denom;
+      if (abs_(denom) >= S(1e-8)) p = o + d * t;
+      else p = p - pn * (dot(p - p0, pn) / len2(pn));
+      rec.front = denom < S(0);
+      n = rec.front ? pn : -pn;
+    }
+  }
+  return true;
+}
 
 template <class R> RTX_DEV void mnee_frame(V3<R> n, V3<R>& t, V3<R>& b) {   // ref: mnee.hpp:299-304
   V3<R> up = (abs_(n.y) < R(0.9)) ? V3<R>{R(0), R(1), R(0)} : V3<R>{R(1), R(0), R(0)};
@@ -27,24 +77,22 @@ template <class R> RTX_DEV void mnee_constraint(V3<R> prev, V3<R> cur, V3<R> nex
   cu = eta * wi_u + wo_u; cv = eta * wi_v + wo_v;
 }
 
-template <class R, class Trace> RTX_DEV bool mnee_reproject(V3<R>& pos, V3<R>& n, int expected, Trace& trace) {   // ref: mnee.hpp:401-437
+template <class S, class R, class Trace> RTX_DEV bool mnee_reproject(const DScene<R>& sc, V3<S>& pos, V3<S>& n, int expected, Trace& trace) {   // ref: mnee.hpp:401-437
+  Hit<R> rec;
+  V3<S> hp, hn;
   for (int d = 0; d < 2; ++d) {
-    Hit<R> rec;
-    Ray<R> sr = {pos, d == 0 ? n : -n};
-    if (trace(sr, R(0), R(0.1), rec)) {
-      if (rec.mat == expected) { pos = rec.p; n = rec.n; return true; }
+    if (mnee_trace(sc, pos, d == 0 ? n : -n, S(0), S(0.1), rec, hp, hn, trace)) {
+      if (rec.mat == expected) { pos = hp; n = hn; return true; }
     }
   }
-  Hit<R> rec;
-  Ray<R> down = {pos + n * R(0.05), -n};
-  if (trace(down, R(0), R(0.2), rec)) {
-    if (rec.mat == expected) { pos = rec.p; n = rec.n; return true; }
+  if (mnee_trace(sc, pos + n * S(0.05), -n, S(0), S(0.2), rec, hp, hn, trace)) {
+    if (rec.mat == expected) { pos = hp; n = hn; return true; }
   }
   return false;
 }
 
 // ref: build_path, mnee.hpp:538-617 — throughput of the chain, then a visibility walk along it
-template <class R, class Trace> RTX_DEV bool mnee_build_path(V3<R> sp, V3<R> lp, const MVertex<R>* ch, int n, R& throughput, Trace& trace) {
+template <class R, class SR, class Trace> RTX_DEV bool mnee_build_path(const DScene<SR>& sc, V3<R> sp, V3<R> lp, const MVertex<R>* ch, int n, R& throughput, Trace& trace) {
   throughput = R(1);
   for (int i = 0; i < n; ++i) {
     V3<R> prev = (i == 0) ? sp : ch[i - 1].p, next = (i == n - 1) ? lp : ch[i + 1].p, cur = ch[i].p;
@@ -53,22 +101,27 @@ template <class R, class Trace> RTX_DEV bool mnee_build_path(V3<R> sp, V3<R> lp,
     R cos_i = abs_(dot(wi, ch[i].n)), cos_t = abs_(dot(wo, ch[i].n));
     R r0 = (R(1) - eta) / (R(1) + eta);
     r0 = r0 * r0;
-    R fr = r0 + (R(1) - r0) * pow(R(1) - cos_i, R(5));
+    R fr;
+    if constexpr (mnee_same<R, SR>::value) fr = r0 + (R(1) - r0) * pow(R(1) - cos_i, R(5));   // std::pow, as the reference
+    else { const R x = R(1) - cos_i, x2 = x * x; fr = r0 + (R(1) - r0) * (x2 * x2 * x); }      // (approximate pow() is NaN for a base rounded below zero)
     R ft = R(1) - fr;
     R geometry = (eta * eta * cos_t) / cos_i;
     throughput *= ft * geometry;
-    if (throughput < R(1e-10)) return false;
+    // A chain of NaNs (the cone sample of an emissive sphere is NaN for a point that rounding put inside that sphere) fails in
+    // the reference at the visibility walk below, whose plane test takes a NaN distance for a hit; here it fails at once.
+    if constexpr (mnee_same<R, SR>::value) { if (throughput < R(1e-10)) return false; }
+    else { if (!(throughput >= R(1e-10))) return false; }
   }
   V3<R> current = sp;
   for (int i = 0; i <= n; ++i) {
     V3<R> target = (i == n) ? lp : ch[i].p;
     V3<R> dir = normalize(target - current);
     R dist = len(target - current);
-    Hit<R> rec;
-    Ray<R> cr = {current, dir};
-    if (trace(cr, R(0.001), dist - R(0.001), rec)) {
+    Hit<SR> rec;
+    V3<R> hp, hn;
+    if (mnee_trace(sc, current, dir, R(0.001), dist - R(0.001), rec, hp, hn, trace)) {
       if (i < n) {
-        R hd = len(rec.p - ch[i].p);
+        R hd = len(hp - ch[i].p);
         if (hd > R(0.01)) return false;
       } else return false;
     }
@@ -79,7 +132,7 @@ template <class R, class Trace> RTX_DEV bool mnee_build_path(V3<R> sp, V3<R> lp,
 
 // ref: solve_manifold, mnee.hpp:442-533 — Gauss-Seidel Newton on the per-vertex refraction
 // constraints with finite-difference 2x2 Jacobians (compute_jacobian_block :354-382, solve_2x2 :387-396)
-template <class R, class Trace> RTX_DEV bool mnee_solve(V3<R> sp, V3<R> lp, MVertex<R>* ch, int n, R& throughput, Trace& trace) {
+template <class R, class SR, class Trace> RTX_DEV bool mnee_solve(const DScene<SR>& sc, V3<R> sp, V3<R> lp, MVertex<R>* ch, int n, R& throughput, Trace& trace) {
   V3<R> tg[kMneeMaxDepth], bt[kMneeMaxDepth];
   for (int i = 0; i < n; ++i) mnee_frame(ch[i].n, tg[i], bt[i]);
   for (int iter = 0; iter < kMneeMaxIter; ++iter) {
@@ -90,7 +143,7 @@ template <class R, class Trace> RTX_DEV bool mnee_solve(V3<R> sp, V3<R> lp, MVer
       R mag = sqrt_(cu[i] * cu[i] + cv[i] * cv[i]);
       max_c = max_(max_c, mag);
     }
-    if (max_c < R(1e-6)) return mnee_build_path(sp, lp, ch, n, throughput, trace);
+    if (max_c < R(1e-6)) return mnee_build_path(sc, sp, lp, ch, n, throughput, trace);
     for (int i = 0; i < n; ++i) {
       V3<R> prev = (i == 0) ? sp : ch[i - 1].p, next = (i == n - 1) ? lp : ch[i + 1].p;
       const R h = R(1e-5);
@@ -106,42 +159,44 @@ template <class R, class Trace> RTX_DEV bool mnee_solve(V3<R> sp, V3<R> lp, MVer
       R mag = sqrt_(st0 * st0 + st1 * st1);
       if (mag > R(0.1)) { R sc = R(0.1) / mag; st0 *= sc; st1 *= sc; }
       ch[i].p = ch[i].p + (tg[i] * st0 + bt[i] * st1);
-      mnee_reproject(ch[i].p, ch[i].n, ch[i].mat, trace);
+      mnee_reproject(sc, ch[i].p, ch[i].n, ch[i].mat, trace);
       mnee_frame(ch[i].n, tg[i], bt[i]);
     }
   }
   return false;
 }
 
-// ref: connect_to_light_straight, mnee.hpp:94-143
-template <class R, class Trace> RTX_DEV bool mnee_straight(const DMaterial<R>* mats, V3<R> sp, V3<R> lp, R& throughput, Trace& trace) {
+// ref: connect_to_light_straight, mnee.hpp:94-143 — the chain of dielectric crossings on the straight line to the light.
+// Returns its length; 0 = no chain (nothing in the way, or something that is not a dielectric).
+template <class R, class SR, class Trace> RTX_DEV int mnee_straight_chain(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<R> sp, V3<R> lp, MVertex<R>* ch, Trace& trace) {
   V3<R> to_light = lp - sp;
   R dist = len(to_light);
   V3<R> dir = to_light * (R(1) / dist);
-  MVertex<R> ch[kMneeMaxDepth];
   int n = 0;
-  Ray<R> probe = {sp, dir};
+  V3<R> probe_o = sp;
   V3<R> cur = sp;
   for (int i = 0; i < kMneeMaxDepth; ++i) {
-    Hit<R> rec;
+    Hit<SR> rec;
+    V3<R> hp, hn;
     R max_t = len(lp - cur) - R(1e-6);
-    if (!trace(probe, R(0.001), max_t, rec)) break;
+    if (!mnee_trace(sc, probe_o, dir, R(0.001), max_t, rec, hp, hn, trace)) break;
     // a quad / disk light in the way has a negative id (the reference indexes its material
     // array with it: undefined behaviour); defined here as "not a dielectric"
-    if (rec.mat < 0 || mats[rec.mat].type != MAT_DIELECTRIC) return false;
-    ch[n].p = rec.p; ch[n].n = rec.n;
-    ch[n].eta = rec.front ? (R(1) / mats[rec.mat].ior) : mats[rec.mat].ior;
+    if (rec.mat < 0 || mats[rec.mat].type != MAT_DIELECTRIC) return 0;
+    ch[n].p = hp; ch[n].n = hn;
+    ch[n].eta = rec.front ? (R(1) / R(mats[rec.mat].ior)) : R(mats[rec.mat].ior);
     ch[n].mat = rec.mat;
     ++n;
-    cur = rec.p;
-    probe = {cur + dir * R(0.001), dir};
+    cur = hp;
+    probe_o = cur + dir * R(0.001);
   }
-  if (n == 0) return false;
-  return mnee_solve(sp, lp, ch, n, throughput, trace);
+  return n;
 }
 
 // Sphere::hit on one sphere: point and face-forwarded normal (ref: engine/sphere.hpp:71-105)
-template <class R> RTX_DEV bool mnee_sphere_hit(const DSphere<R>& s, const Ray<R>& r, V3<R>& p, V3<R>& n) {
+template <class R, class SR> RTX_DEV bool mnee_sphere_hit(const DSphere<SR>& s0, const Ray<R>& r, V3<R>& p, V3<R>& n) {
+  DSphere<R> s;
+  s.c[0] = R(s0.c[0]); s.c[1] = R(s0.c[1]); s.c[2] = R(s0.c[2]); s.radius = R(s0.radius); s.mat = s0.mat; s.pad = 0;
   R t;
   if (!sphere_t(s, r, R(0.001), R(1e9), t)) return false;
   p = at(r, t);
@@ -150,18 +205,20 @@ template <class R> RTX_DEV bool mnee_sphere_hit(const DSphere<R>& s, const Ray<R
   return true;
 }
 
-// ref: try_sphere_seed_path, mnee.hpp:194-295
-template <class R, class Trace> RTX_DEV bool mnee_sphere_seed(const DSphere<R>& sph, const DMaterial<R>& m, V3<R> sp, V3<R> lp, R& throughput, Trace& trace) {
-  V3<R> c = mk3(sph.c);
+// ref: try_sphere_seed_path, mnee.hpp:194-295 — the two-vertex seed chain through one dielectric sphere.  Returns 2, or 0.
+template <class R, class SR> RTX_DEV int mnee_sphere_seed_chain(const DSphere<SR>& sph0, const DMaterial<SR>& m0, V3<R> sp, V3<R> lp, MVertex<R>* ch) {
+  struct { R radius; int mat; } sph = {R(sph0.radius), sph0.mat};
+  struct { R ior; } m = {R(m0.ior)};
+  V3<R> c = {R(sph0.c[0]), R(sph0.c[1]), R(sph0.c[2])};
   V3<R> pts[2], nrm[2];
   for (int k = 0; k < 2; ++k) {
     V3<R> origin = k == 0 ? sp : lp;
     V3<R> dir = k == 0 ? normalize(lp - sp) : normalize(sp - lp);
     Ray<R> rr = {origin, dir};
-    if (!mnee_sphere_hit(sph, rr, pts[k], nrm[k])) {
+    if (!mnee_sphere_hit(sph0, rr, pts[k], nrm[k])) {
       V3<R> to_center = c - origin;
       R proj = dot(to_center, dir);
-      if (proj < R(0)) return false;
+      if (proj < R(0)) return 0;
       V3<R> closest = origin + dir * proj;
       R da = len(c - closest);
       if (da >= sph.radius) pts[k] = c + normalize(closest - c) * sph.radius;
@@ -169,25 +226,33 @@ template <class R, class Trace> RTX_DEV bool mnee_sphere_seed(const DSphere<R>& 
       nrm[k] = normalize(pts[k] - c);
     }
   }
-  MVertex<R> ch[kMneeMaxDepth];
   ch[0].p = pts[0]; ch[0].n = nrm[0]; ch[0].eta = R(1) / m.ior; ch[0].mat = sph.mat;
   ch[1].p = pts[1]; ch[1].n = -nrm[1]; ch[1].eta = m.ior; ch[1].mat = sph.mat;
-  return mnee_solve(sp, lp, ch, 2, throughput, trace);
+  return 2;
 }
 
-// ref: connect_to_light, mnee.hpp:73-88, with connect_to_light_seeded, :152-189
-template <class R, class Trace> RTX_DEV bool mnee_connect(const DScene<R>& sc, const DMaterial<R>* mats, V3<R> sp, V3<R> lp, R& throughput, Trace& trace) {
-  if (mnee_straight(mats, sp, lp, throughput, trace)) return true;
-  for (int i = 0; i < sc.n_spheres; ++i) {
-    const DSphere<R>& sph = sc.spheres[i];
-    const DMaterial<R>& m = mats[sph.mat];
-    if (m.type != MAT_DIELECTRIC) continue;
-    V3<R> to_sphere = mk3(sph.c) - sp, to_light = lp - sp;
-    R ds = len(to_sphere), dl = len(to_light);
-    if (ds > dl + sph.radius) continue;
-    if (ds < sph.radius) continue;
-    if (dot(to_sphere * (R(1) / ds), to_light * (R(1) / dl)) < R(0)) continue;
-    if (mnee_sphere_seed(sph, m, sp, lp, throughput, trace)) return true;
+// ref: connect_to_light, mnee.hpp:73-88, with connect_to_light_seeded, :152-189: the straight chain first, then a seed chain
+// through every dielectric sphere that lies towards the light; the first chain the solver brings to convergence wins.  (One
+// loop over the attempts, so that the solver and its closest-hit queries are instantiated once.)
+template <class R, class SR, class Trace> RTX_DEV bool mnee_connect(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<R> sp, V3<R> lp, R& throughput, Trace& trace) {
+  for (int i = -1; i < sc.n_spheres; ++i) {
+    MVertex<R> ch[kMneeMaxDepth];
+    int n = 0;
+    if (i < 0) {
+      n = mnee_straight_chain(sc, mats, sp, lp, ch, trace);
+    } else {
+      const DSphere<SR>& sph = sc.spheres[i];
+      const DMaterial<SR>& m = mats[sph.mat];
+      if (m.type != MAT_DIELECTRIC) continue;
+      V3<R> to_sphere = V3<R>{R(sph.c[0]), R(sph.c[1]), R(sph.c[2])} - sp, to_light = lp - sp;
+      R ds = len(to_sphere), dl = len(to_light);
+      if (ds > dl + R(sph.radius)) continue;
+      if (ds < R(sph.radius)) continue;
+      if (dot(to_sphere * (R(1) / ds), to_light * (R(1) / dl)) < R(0)) continue;
+      n = mnee_sphere_seed_chain(sph, m, sp, lp, ch);
+    }
+    if (n == 0) continue;
+    if (mnee_solve(sc, sp, lp, ch, n, throughput, trace)) return true;
   }
   return false;
 }
@@ -201,83 +266,81 @@ template <class R> RTX_DEV void mnee_pair(PathKey key, int bounce, int j, R& a, 
 }
 
 // ref: MNEE::evaluate, mnee.hpp:632-763.  Returns whether any light contributed.
-template <class R, class Trace> RTX_DEV bool mnee_evaluate(const DScene<R>& sc, const DMaterial<R>* mats, V3<R> hp, PathKey key, int bounce, V3<R>& contribution, Trace& trace) {
-  contribution = {R(0), R(0), R(0)};
+template <class SR, class Trace> RTX_DEV bool mnee_evaluate(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<SR> hp0, PathKey key, int bounce, V3<SR>& contribution_out, Trace& trace) {
+  using R = double;   // the type the walk computes in; SR is the scene's
+  auto mk3 = [](const SR* a) { return V3<R>{R(a[0]), R(a[1]), R(a[2])}; };
+  const V3<R> hp = v3_to<R>(hp0);
+  V3<R> contribution = {R(0), R(0), R(0)};
   bool any = false;
-  int j = 0;
   const R two_pi = R(2) * R(3.14159265358979323846);
-  for (int i = 0; i < sc.n_quads; ++i) {
-    const DQuad<R>& q = sc.quads[i];
+  // the lights in the reference's order: quads, disks, then the spheres (in index order) whose material is emissive; light j
+  // draws the j-th pair of uniforms.  One loop, so that mnee_connect is instantiated once.
+  const int nq = sc.n_quads, nd = sc.n_disks, total = nq + nd + sc.n_emissive;
+  for (int j = 0; j < total; ++j) {
     R u, v;
-    mnee_pair(key, bounce, j++, u, v);
-    V3<R> lp = mk3(q.corner) + (mk3(q.eu) * u + mk3(q.ev) * v);   // ref: QuadLight::sample_point, primitives.hpp:258-262
-    V3<R> ln = mk3(q.n);
+    mnee_pair(key, bounce, j, u, v);
+    V3<R> lp, ln, Le, sd = {R(0), R(0), R(0)};
+    R area = R(0), ctm = R(0);
+    const bool sphere = j >= nq + nd;
+    if (j < nq) {
+      const DQuad<SR>& q = sc.quads[j];
+      lp = mk3(q.corner) + (mk3(q.eu) * u + mk3(q.ev) * v);   // ref: QuadLight::sample_point, primitives.hpp:258-262
+      ln = mk3(q.n); Le = mk3(q.Le); area = R(q.area);
+    } else if (!sphere) {
+      const DDisk<SR>& dl = sc.disks[j - nq];
+      lp = mk3(dl.c);   // ref: DiskLight::sample_point, primitives.hpp:350-384
+      R sx = R(2) * u - R(1), sy = R(2) * v - R(1);
+      if (!(sx == R(0) && sy == R(0))) {
+        R rs, theta;
+        if (abs_(sx) > abs_(sy)) { rs = sx; theta = (Consts<R>::pi / R(4)) * (sy / sx); }
+        else { rs = sy; theta = (Consts<R>::pi / R(2)) - (Consts<R>::pi / R(4)) * (sx / sy); }
+        R st, ct;
+        sincos_(theta, &st, &ct);
+        R ar = R(dl.radius) * rs;
+        lp = lp + (mk3(dl.tan) * (ar * ct) + mk3(dl.bit) * (ar * st));
+      }
+      ln = mk3(dl.n); Le = mk3(dl.Le); area = R(dl.area);
+    } else {
+      const DSphere<SR>& sph = sc.spheres[sc.emissive[j - nq - nd]];
+      V3<R> to_sphere = mk3(sph.c) - hp;
+      R dc = len(to_sphere);
+      V3<R> w3 = to_sphere * (R(1) / dc);
+      const R radius = R(sph.radius);
+      ctm = sqrt_(R(1) - (radius * radius) / (dc * dc));
+      if (ctm < R(0)) ctm = R(0);
+      const R r1 = u, r2 = v;
+      R ct = R(1) + r1 * (ctm - R(1));
+      R sn = sqrt_(R(1) - ct * ct);
+      R phi = two_pi * r2;
+      V3<R> uv = (abs_(w3.x) > R(0.9)) ? V3<R>{R(0), R(1), R(0)} : V3<R>{R(1), R(0), R(0)};
+      uv = normalize(cross(w3, uv));
+      V3<R> vv = cross(w3, uv);
+      R sphi, cphi;
+      sincos_(phi, &sphi, &cphi);
+      sd = uv * (sn * cphi) + (vv * (sn * sphi) + w3 * ct);
+      R t = dc * ct - sqrt_(radius * radius - dc * dc * (R(1) - ct * ct));
+      lp = hp + sd * t;
+      ln = normalize(lp - mk3(sph.c));
+      Le = mk3(mats[sph.mat].emission);
+    }
     R w;
     if (mnee_connect(sc, mats, hp, lp, w, trace)) {
-      V3<R> to_light = lp - hp;
-      R d2 = len2(to_light);
-      R cl = abs_(dot(ln, normalize(-to_light)));
-      R lpdf = d2 / (q.area * cl);
-      contribution = contribution + mk3(q.Le) * (w * cl / (d2 * lpdf));
+      if (sphere) {
+        R solid = two_pi * (R(1) - ctm);
+        R pdf = R(1) / solid;
+        R cal = abs_(dot(ln, -sd));
+        contribution = contribution + Le * (w * cal / pdf);
+      } else {
+        V3<R> to_light = lp - hp;
+        R d2 = len2(to_light);
+        R cl = abs_(dot(ln, normalize(-to_light)));
+        R lpdf = d2 / (area * cl);
+        contribution = contribution + Le * (w * cl / (d2 * lpdf));
+      }
       any = true;
     }
   }
-  for (int i = 0; i < sc.n_disks; ++i) {
-    const DDisk<R>& dl = sc.disks[i];
-    R u, v;
-    mnee_pair(key, bounce, j++, u, v);
-    V3<R> lp = mk3(dl.c);   // ref: DiskLight::sample_point, primitives.hpp:350-384
-    R sx = R(2) * u - R(1), sy = R(2) * v - R(1);
-    if (!(sx == R(0) && sy == R(0))) {
-      R rs, theta;
-      if (abs_(sx) > abs_(sy)) { rs = sx; theta = (Consts<R>::pi / R(4)) * (sy / sx); }
-      else { rs = sy; theta = (Consts<R>::pi / R(2)) - (Consts<R>::pi / R(4)) * (sx / sy); }
-      R st, ct;
-      sincos_(theta, &st, &ct);
-      R ar = dl.radius * rs;
-      lp = lp + (mk3(dl.tan) * (ar * ct) + mk3(dl.bit) * (ar * st));
-    }
-    V3<R> ln = mk3(dl.n);
-    R w;
-    if (mnee_connect(sc, mats, hp, lp, w, trace)) {
-      V3<R> to_light = lp - hp;
-      R d2 = len2(to_light);
-      R cl = abs_(dot(ln, normalize(-to_light)));
-      R lpdf = d2 / (dl.area * cl);
-      contribution = contribution + mk3(dl.Le) * (w * cl / (d2 * lpdf));
-      any = true;
-    }
-  }
-  for (int e = 0; e < sc.n_emissive; ++e) {   // spheres in index order whose material is emissive
-    const DSphere<R>& sph = sc.spheres[sc.emissive[e]];
-    V3<R> to_sphere = mk3(sph.c) - hp;
-    R dc = len(to_sphere);
-    V3<R> w3 = to_sphere * (R(1) / dc);
-    R ctm = sqrt_(R(1) - (sph.radius * sph.radius) / (dc * dc));
-    if (ctm < R(0)) ctm = R(0);
-    R r1, r2;
-    mnee_pair(key, bounce, j++, r1, r2);
-    R ct = R(1) + r1 * (ctm - R(1));
-    R sn = sqrt_(R(1) - ct * ct);
-    R phi = two_pi * r2;
-    V3<R> uv = (abs_(w3.x) > R(0.9)) ? V3<R>{R(0), R(1), R(0)} : V3<R>{R(1), R(0), R(0)};
-    uv = normalize(cross(w3, uv));
-    V3<R> vv = cross(w3, uv);
-    R sphi, cphi;
-    sincos_(phi, &sphi, &cphi);
-    V3<R> sd = uv * (sn * cphi) + (vv * (sn * sphi) + w3 * ct);
-    R t = dc * ct - sqrt_(sph.radius * sph.radius - dc * dc * (R(1) - ct * ct));
-    V3<R> lp = hp + sd * t;
-    V3<R> ln = normalize(lp - mk3(sph.c));
-    R w;
-    if (mnee_connect(sc, mats, hp, lp, w, trace)) {
-      R solid = two_pi * (R(1) - ctm);
-      R pdf = R(1) / solid;
-      R cal = abs_(dot(ln, -sd));
-      contribution = contribution + mk3(mats[sph.mat].emission) * (w * cal / pdf);
-      any = true;
-    }
-  }
+  contribution_out = v3_to<SR>(contribution);
   return any;
 }
 

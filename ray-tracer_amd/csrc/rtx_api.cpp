@@ -436,26 +436,26 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   P.n_chunks = (P.spp + P.chunk_spp - 1) / P.chunk_spp;
   P.seed = s->seed;
   P.clamp_max = s->clamp_max;
-  P.rng = (s->rng == RTX_RNG_PCG4D || (s->rng == RTX_RNG_AUTO && s->precision == RTX_PRECISION_F32 && !(s->use_mnee && s->use_nee && s->mode == RTX_MODE_PATHTRACE))) ? 1 /* RNG_PCG4D */ : 0;
+  P.rng = (s->rng == RTX_RNG_PCG4D || (s->rng == RTX_RNG_AUTO && s->precision == RTX_PRECISION_F32)) ? 1 /* RNG_PCG4D */ : 0;
   for (int i = 0; i < 3; ++i) { P.bg[i] = s->background_color[i]; P.bg_top[i] = s->background_top[i]; P.bg_bottom[i] = s->background_bottom[i]; }
 
   const unsigned long long npix = (unsigned long long)P.rows * P.width;
   rtx_stats st;
   memset(&st, 0, sizeof st);
   if (npix == 0) { if (stats) *stats = st; return RTX_OK; }
-  // Manifold next event estimation runs in the double-precision fused kernel only (its Newton solver's
-  // tolerances leave no room for single precision): a single-precision request is promoted.
+  // Manifold next event estimation runs in the fused kernels: in double precision as the reference computes it, in single
+  // precision with single-precision traces around a double-precision manifold walk.
   const bool whitted = s->mode == RTX_MODE_WHITTED;
   const bool bdpt = s->mode == RTX_MODE_BDPT;
   const bool photon = s->mode == RTX_MODE_PATHPHOTON;
   const bool mnee = !whitted && !bdpt && !photon && s->use_mnee != 0 && s->use_nee != 0;
-  const bool f64 = s->precision == RTX_PRECISION_F64 || mnee;
+  const bool f64 = s->precision == RTX_PRECISION_F64;
   const bool f64_req = f64;
   // AUTO: scenes that walk a tree run the queue-based pipeline (its traversal kernels hold 2-4x
   // the waves of the fused kernel, measured 1.6x faster on a 10 M-triangle scene); scenes small
   // enough for the linear / flat intersection stay fused (no queue traffic, measured 2-3x faster).
   int pipeline = s->pipeline;
-  if (pipeline == RTX_PIPELINE_AUTO) pipeline = (!f64_req && !whitted && !bdpt && !photon && c->scene.n_prims > kLinearMaxPrims) ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED;
+  if (pipeline == RTX_PIPELINE_AUTO) pipeline = (!f64_req && !whitted && !bdpt && !photon && !mnee && c->scene.n_prims > kLinearMaxPrims) ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED;
   if (pipeline == RTX_PIPELINE_WAVEFRONT && photon) return fail(RTX_ERR_UNSUPPORTED, "the PathPhoton mode is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && bdpt) return fail(RTX_ERR_UNSUPPORTED, "the BDPT mode is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && whitted) return fail(RTX_ERR_UNSUPPORTED, "the Whitted mode is implemented by the fused pipeline only");
@@ -501,6 +501,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     L.mode = whitted ? MODE_TREE_UV : c->scene.fused_mode(f64);
     if (photon && L.mode != MODE_FLAT) L.mode = MODE_TREE_UV;   // PathPhoton: the flat instance (single precision, small untextured scenes) or the general one
     if (bdpt && L.mode == MODE_TREE) L.mode = MODE_TREE_UV;
+    if (mnee && !f64 && L.mode == MODE_TREE) L.mode = MODE_TREE_UV;   // the single-precision MNEE instances: flat or general
     L.integ = whitted ? INTEG_WHITTED : bdpt ? INTEG_BDPT : photon ? INTEG_PATHPHOTON : mnee ? INTEG_PATH_MNEE : INTEG_PATH;
     const size_t mat_bytes = (size_t)c->scene.dev_f.n_mats * (f64 ? sizeof(DMaterial<double>) : sizeof(DMaterial<float>));
     L.lds_mats = mat_bytes <= kMaxLdsMaterialBytes;
