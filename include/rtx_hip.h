@@ -153,7 +153,9 @@ typedef struct rtx_stats {
   uint32_t pipeline_used;    /* RTX_PIPELINE_FUSED or _WAVEFRONT */
   uint32_t precision_used;   /* RTX_PRECISION_* the render ran in */
   uint32_t reserved_;
-  double seconds_photon_pass;/* PathPhoton: wall time of the photon pass (trace kernel, kd-tree build on the host, uploads); else 0 */
+  double seconds_photon_pass;/* PathPhoton: wall time of the photon pass (trace kernel, kd-tree build on the host, uploads); ~0 when the context reuses the
+                              * map of an earlier render (same scene upload, seed, generator, caustic_photon_count, precision); else 0.  rays_closest
+                              * includes the pass's queries in both cases */
   /* queue-based pipeline only (0 otherwise): the closest-hit traversal kernel of the ray queue */
   double seconds_extend;     /* device time of its launches, summed (HIP events around each) */
   uint64_t nodes_visited;    /* node records it fetched and tested */

@@ -130,6 +130,14 @@ __global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4
     __shared__ __align__(16) R photon_table[photon_table_words<R>()];
     PhotonCand<R> pc;
     pc.d2 = cand_d2[threadIdx.x >> 6]; pc.id = cand_id[threadIdx.x >> 6];
+    pc.cap = kPhotonCand; pc.d2_alt = nullptr; pc.id_alt = nullptr;
+    if (P.ph_cand_cap > 0) {   // more photons per estimate than the LDS list holds: this wave's two lists in device memory
+      const size_t cap = (size_t)P.ph_cand_cap, wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+      char* base = (char*)P.ph_cand + wave * cap * 2 * (sizeof(R) + sizeof(int));
+      pc.d2 = (R*)base; pc.d2_alt = pc.d2 + cap;
+      pc.id = (int*)(pc.d2_alt + cap); pc.id_alt = pc.id + cap;
+      pc.cap = P.ph_cand_cap;
+    }
     photon_stage_table<R>(P, photon_table, pc);
     __syncthreads();
     for (;;) {

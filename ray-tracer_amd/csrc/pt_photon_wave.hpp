@@ -8,7 +8,8 @@
 //    photon_query) and stops at subtrees of DRenderParams::ph_bucket photons (by default 64^3: maps below that size are
 //    not walked at all); a subtree is searched through bounding boxes of its runs of 64 photons, one box or one photon per
 //    lane, read with coalesced loads (photon_scan);
-//  * photons nearer than the current bound are appended to a candidate list in LDS (kPhotonCand entries per wave); when
+//  * photons nearer than the current bound are appended to a candidate list (in LDS, kPhotonCand entries per wave, for k up to
+//    kPhotonMaxGather; in device memory for larger k, see photon_select_list); when
 //    the list runs full, and once at the end, the k nearest are selected from it by a bit-wise search for the k-th
 //    smallest distance (the order of non-negative IEEE numbers is the order of their bit patterns), counted with ballots;
 //    the k-th distance becomes the new bound;
@@ -48,6 +49,8 @@ template <class R> constexpr int photon_table_words() {   // in units of R
 // lds_groups, lds_runs: whether the group boxes (at lbox[g]) and the run boxes (at lbox[n_groups + r]) are in it.
 template <class R> struct PhotonCand {
   R* d2; int* id;
+  int cap;                 // entries the list holds: kPhotonCand in LDS, DRenderParams::ph_cand_cap in device memory
+  R* d2_alt; int* id_alt;  // device-memory lists only: the second list a selection writes its survivors to
   const DPhotonNode<R>* top;
   const DPhotonBox<R>* lbox;
   bool lds_groups, lds_runs;
@@ -106,8 +109,47 @@ template <class R> RTX_DEV R box_distance2(const DPhotonBox<R> bx, const V3<R> p
   return (dx * dx + dy * dy + dz * dz) * R(0.9999);
 }
 
+// The same selection for a list of any length in device memory (k above kPhotonMaxGather): the keys are read again from the list
+// for every bit of the search instead of being held in registers, and the survivors go to the wave's second list, which then
+// becomes the list (compacting in place would overwrite entries that are still to be read).
+template <class R> RTX_DEV R photon_select_list(PhotonCand<R>& pc, int& n, const int k, const int lane) {
+  using K = decltype(dist_key(R(0)));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the list entries other lanes appended are read below
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  K kth = 0;
+  for (int bit = (int)sizeof(K) * 8 - 2; bit >= 0; --bit) {
+    const K trial = kth | (K(1) << bit);
+    int below = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int slot = base + lane;
+      const K key = slot < n ? dist_key(pc.d2[slot]) : ~K(0);
+      below += (int)__popcll(__ballot(key < trial));
+    }
+    if (below < k) kth = trial;
+  }
+  int out = 0;
+  for (int pass = 0; pass < 2; ++pass)   // the keys below the k-th, then the keys equal to it as far as k entries go, both in list order
+    for (int base = 0; base < n; base += 64) {
+      const int slot = base + lane;
+      const K key = slot < n ? dist_key(pc.d2[slot]) : ~K(0);
+      const bool t = slot < n && (pass == 0 ? key < kth : key == kth);
+      const unsigned long long m = __ballot(t);
+      if (t) { const int pos = out + lanes_below(m); if (pos < k) { pc.d2_alt[pos] = key_dist(key); pc.id_alt[pos] = pc.id[slot]; } }
+      out += (int)__popcll(m);
+    }
+  R* td = pc.d2; pc.d2 = pc.d2_alt; pc.d2_alt = td;
+  int* ti = pc.id; pc.id = pc.id_alt; pc.id_alt = ti;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  n = k;
+  return key_dist(kth);
+}
+
 // Cuts the candidate list (n > k entries) down to its k nearest and returns the k-th smallest distance.
-template <class R> RTX_DEV R photon_select(PhotonCand<R> pc, int& n, const int k, const int lane) {
+template <class R> RTX_DEV R photon_select(PhotonCand<R>& pc, int& n, const int k, const int lane) {
+  if (pc.cap != kPhotonCand) return photon_select_list(pc, n, k, lane);
   using K = decltype(dist_key(R(0)));
   K key[kPhotonCandPerLane];
   int id[kPhotonCandPerLane];
@@ -153,13 +195,13 @@ template <class R> RTX_DEV R photon_select(PhotonCand<R> pc, int& n, const int k
 // in space, so the host keeps the box of every run of 64 photons and of every group of 64 runs.  One lane tests one group
 // box, then one run box of a group in reach, then one photon of a run in reach.  Adds to the candidate list (n entries) and
 // tightens `bound`.
-template <class R> RTX_DEV void photon_scan(const DRenderParams& P, const V3<R> pos, const int start, const int end, PhotonCand<R> pc, int& n, R& bound, const int lane) {
+template <class R> RTX_DEV void photon_scan(const DRenderParams& P, const V3<R> pos, const int start, const int end, PhotonCand<R>& pc, int& n, R& bound, const int lane) {
   const DPhotonNode<R>* nodes = (const DPhotonNode<R>*)P.ph_nodes;
   const DPhotonBox<R>* boxes = (const DPhotonBox<R>*)P.ph_boxes;     // box r: photons [64 r, 64 r + 64)
   const int n_groups = ((P.n_photons + 63) / 64 + 63) / 64;
   const DPhotonBox<R>* groups = boxes + (P.n_photons + 63) / 64;      // box g: runs [64 g, 64 g + 64)
-  const int k = P.gather_k;
-  const int select_at = (kPhotonCand - 64 < k + 64) ? kPhotonCand - 64 : k + 64;   // list length that triggers a selection (> k)
+  const int k = P.gather_k < P.n_photons ? P.gather_k : P.n_photons;
+  const int select_at = (pc.cap - 64 < k + 64) ? pc.cap - 64 : k + 64;   // list length that triggers a selection (> k)
   const int run0 = start >> 6, run1 = (end - 1) >> 6;
   for (int gb = run0 >> 6; gb <= run1 >> 6; gb += 64) {
     R group_d2 = bound;
@@ -200,7 +242,7 @@ template <class R> RTX_DEV void photon_scan(const DRenderParams& P, const V3<R> 
           bool take = i >= start && i < end && d2 < bound;
           unsigned long long m = __ballot(take);
           if (m == 0ull) continue;
-          if (n + (int)__popcll(m) > kPhotonCand) {   // n > kPhotonCand - 64 >= k
+          if (n + (int)__popcll(m) > pc.cap) {   // n > cap - 64 >= k
             bound = photon_select(pc, n, k, lane);
             take = take && d2 < bound;
             m = __ballot(take);
@@ -226,7 +268,7 @@ template <class R> RTX_DEV void photon_scan(const DRenderParams& P, const V3<R> 
 template <class R> RTX_DEV V3<R> photon_query(const DRenderParams& P, const V3<R> pos, const V3<R> normal, PhotonCand<R> pc, const int lane) {
   const DPhotonNode<R>* nodes = (const DPhotonNode<R>*)P.ph_nodes;
   const DPhotonData<R>* data = (const DPhotonData<R>*)P.ph_data;
-  const int k = P.gather_k;
+  const int k = P.gather_k < P.n_photons ? P.gather_k : P.n_photons;   // there are no more photons than that to keep
   const R radius = R(P.gather_radius);
   R bound = radius * radius;   // a photon is a candidate if it is nearer than this
   int n = 0;
@@ -266,7 +308,7 @@ template <class R> RTX_DEV V3<R> photon_query(const DRenderParams& P, const V3<R
     const DPhotonNode<R> q = level < kPhotonTopLevels ? pc.top[heap] : nodes[mid];
     const R d2 = len2(V3<R>{q.p[0], q.p[1], q.p[2]} - pos);
     if (d2 < bound) {
-      if (n == kPhotonCand) bound = photon_select(pc, n, k, lane);
+      if (n == pc.cap) bound = photon_select(pc, n, k, lane);
       if (d2 < bound) {
         if (lane == 0) { pc.d2[n] = d2; pc.id[n] = mid; }
         ++n;
@@ -280,6 +322,7 @@ template <class R> RTX_DEV V3<R> photon_query(const DRenderParams& P, const V3<R
   }
   if (n == 0) return {R(0), R(0), R(0)};
   if (n > k) photon_select(pc, n, k, lane);
+  if (pc.cap != kPhotonCand) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
   __builtin_amdgcn_wave_barrier();
   R r2 = R(0);
   for (int slot = lane; slot < n; slot += 64) r2 = max_(r2, pc.d2[slot]);

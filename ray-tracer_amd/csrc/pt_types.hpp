@@ -117,7 +117,10 @@ struct DRenderParams {
   // bounding boxes of its photons (DPhotonBox<R>): one per run of 64 photons, then one per group of 64 runs
   const void* ph_nodes; const void* ph_data; const void* ph_boxes;
   int32_t n_photons, gather_k;
-  int32_t ph_bucket, ph_pad;                // a kd subtree of at most ph_bucket photons is searched through its boxes, not walked
+  int32_t ph_bucket, ph_cand_cap;           // a kd subtree of at most ph_bucket photons is searched through its boxes, not walked
+  // gather_k above kPhotonMaxGather: the candidate lists of the density estimate live in device memory instead of LDS, two lists
+  // of ph_cand_cap entries (distances, then photon numbers) per wave of the grid; 0 / NULL otherwise
+  void* ph_cand;
   double gather_radius;
 };
 
@@ -126,7 +129,7 @@ struct DRenderParams {
 // (16 spp): walking down to 64 photons 896 ms, 1024: 470, 16384: 235, no walk: 156.
 constexpr int kPhotonBucket = 64 * 64 * 64;
 constexpr unsigned long long kPhotonMaxCount = 1ull << 26;   // caustic photons per render (5 GB of double-precision staging on the host)
-constexpr int kPhotonMaxGather = 128;   // largest photon_gather_count the density estimate supports
+constexpr int kPhotonMaxGather = 128;   // largest photon_gather_count whose candidate list fits the LDS of a wave; larger counts keep the list in device memory
 struct DPhotonLight { int32_t sphere; uint32_t first, count; int32_t pad; double power[3]; };   // photons [first, first + count) leave this emissive sphere
 template <class R> struct DPhotonNode { R p[3]; int32_t axis; };       // kd-tree in the reference's implicit layout: the median of a range sits at its middle
 template <class R> struct DPhotonData { R dir[3]; R power[3]; };

@@ -94,8 +94,18 @@ struct rtx_ctx {
   DCamera<float> cam_f;
   DCamera<double> cam_d;
   DeviceBuffer partial, film, counters, rays, hits, post_in, post_out, bdpt_store;
-  DeviceBuffer ph_lights, ph_targets, ph_out, ph_nodes, ph_data, ph_boxes;   // PathPhoton: photon pass plan, its raw output, the kd-tree
+  DeviceBuffer ph_lights, ph_targets, ph_out, ph_nodes, ph_data, ph_boxes, ph_cand;   // PathPhoton: photon pass plan, its raw output, the kd-tree
   WavefrontPool wf;         // wavefront-pipeline queues, allocated on first use
+  // The photon map in ph_nodes / ph_data / ph_boxes and what it was built from: a render with the same inputs reuses it
+  // (the map depends on the scene, the seed and generator, the photon count and the precision, not on camera or samples).
+  struct PhotonMapKey {
+    bool valid = false;
+    unsigned long long scene_generation = 0, photon_count = 0;
+    uint32_t seed = 0; int rng = 0, f64 = 0, bucket = 0;
+    int32_t n_photons = 0;              // photons stored
+    unsigned long long closest = 0;     // closest-hit queries the photon pass made
+  } ph_map;
+  unsigned long long scene_generation = 0;   // counts rtx_upload_scene calls
   // Multi-device context (rtx_create_multi): this is the context of the first listed device; `peers` are the contexts of the
   // others (owned), `gather` holds the peers' rows on this device until they are interleaved into the caller's film.
   bool multi = false;
@@ -133,11 +143,13 @@ void photon_build_tree(PhotonKey* ph, size_t start, size_t end, int depth) {
     photon_build_tree(ph, mid + 1, end, depth + 1);
   }
 }
-template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderParams& P, const DScene<R>& sc, size_t lds_bytes, hipStream_t stream) {
+// `reused` comes back true when the context already held the map of these inputs (nothing was traced or built).
+template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderParams& P, const DScene<R>& sc, size_t lds_bytes, hipStream_t stream, bool& reused) {
+  reused = false;
   const double kPi = 3.14159265358979323846;
   const std::vector<rtx_sphere>& sph = c->scene.h_spheres;
   const std::vector<rtx_material>& mats = c->scene.h_materials;
-  P.ph_nodes = nullptr; P.ph_data = nullptr; P.ph_boxes = nullptr; P.n_photons = 0; P.ph_bucket = kPhotonBucket; P.ph_pad = 0;
+  P.ph_nodes = nullptr; P.ph_data = nullptr; P.ph_boxes = nullptr; P.n_photons = 0; P.ph_bucket = kPhotonBucket; P.ph_cand = nullptr; P.ph_cand_cap = 0;
   if (const char* e = std::getenv("RTX_PHOTON_BUCKET")) { const int v = std::atoi(e); if (v >= 1) P.ph_bucket = v; }   // tests: small maps walk the tree too
   P.gather_k = s->photon_gather_count; P.gather_radius = (double)s->caustic_gather_radius;
   std::vector<size_t> lights;
@@ -167,6 +179,15 @@ template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderPar
     total += n;
   }
   if (total == 0) return RTX_OK;
+  const int is_f64 = sizeof(R) == sizeof(double) ? 1 : 0;
+  rtx_ctx::PhotonMapKey& key = c->ph_map;
+  if (key.valid && key.scene_generation == c->scene_generation && key.photon_count == (unsigned long long)s->caustic_photon_count && key.seed == P.seed && key.rng == P.rng &&
+      key.f64 == is_f64 && key.bucket == P.ph_bucket) {
+    reused = true;
+    if (key.n_photons > 0) { P.ph_nodes = c->ph_nodes.ptr; P.ph_data = c->ph_data.ptr; P.ph_boxes = c->ph_boxes.ptr; P.n_photons = key.n_photons; }
+    return RTX_OK;
+  }
+  key.valid = false;
   // the host stages every photon record once (10 values each) to build the kd-tree: bounded to what a host can hold
   if (total > kPhotonMaxCount) return fail(RTX_ERR_INVALID_ARGUMENT, "caustic_photon_count %llu is too large (at most %llu)", (unsigned long long)s->caustic_photon_count, (unsigned long long)kPhotonMaxCount);
   const uint32_t n = (uint32_t)total;
@@ -177,8 +198,14 @@ template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderPar
                       (DCounters*)c->counters.ptr, lds_bytes, stream);
   HIP_TRY(hipGetLastError());
   std::vector<R> raw((size_t)n * 10);
+  DCounters pass_counters;
   HIP_TRY(hipMemcpyAsync(raw.data(), c->ph_out.ptr, raw.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(&pass_counters, c->counters.ptr, sizeof pass_counters, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
+  auto remember = [&](int32_t stored) {
+    key.valid = true; key.scene_generation = c->scene_generation; key.photon_count = (unsigned long long)s->caustic_photon_count; key.seed = P.seed; key.rng = P.rng;
+    key.f64 = is_f64; key.bucket = P.ph_bucket; key.n_photons = stored; key.closest = pass_counters.closest;
+  };
   std::vector<PhotonKey> ph;
   ph.reserve(n);
   for (uint32_t i = 0; i < n; ++i) {   // in emission order, as the reference's push_back sequence
@@ -188,7 +215,7 @@ template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderPar
     q.idx = i; q.axis = 0;
     ph.push_back(q);
   }
-  if (ph.empty()) return RTX_OK;
+  if (ph.empty()) { remember(0); return RTX_OK; }
   photon_build_tree(ph.data(), 0, ph.size(), 0);
   std::vector<DPhotonNode<R>> nodes(ph.size());
   std::vector<DPhotonData<R>> data(ph.size());
@@ -217,6 +244,7 @@ template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderPar
       !c->ph_boxes.upload(boxes.data(), boxes.size() * sizeof(DPhotonBox<R>)))
     return fail(RTX_ERR_OUT_OF_MEMORY, "photon map (%zu photons)", ph.size());
   P.ph_nodes = c->ph_nodes.ptr; P.ph_data = c->ph_data.ptr; P.ph_boxes = c->ph_boxes.ptr; P.n_photons = (int32_t)ph.size();
+  remember(P.n_photons);
   return RTX_OK;
 }
 }  // namespace
@@ -323,7 +351,7 @@ int rtx_destroy(rtx_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   c->scene.release();
   c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release(); c->post_in.release(); c->post_out.release(); c->bdpt_store.release();
-  c->ph_lights.release(); c->ph_targets.release(); c->ph_out.release(); c->ph_nodes.release(); c->ph_data.release(); c->ph_boxes.release();
+  c->ph_lights.release(); c->ph_targets.release(); c->ph_out.release(); c->ph_nodes.release(); c->ph_data.release(); c->ph_boxes.release(); c->ph_cand.release();
   c->wf.release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -337,6 +365,8 @@ static int upload_impl(rtx_ctx* c, const rtx_scene_desc* d) {
   if (!c || !d) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
   c->has_scene = false;
   for (rtx_ctx* p : c->peers) p->has_scene = false;
+  ++c->scene_generation;
+  for (rtx_ctx* p : c->peers) ++p->scene_generation;
   std::string err;
   ScenePrep prep;   // the reference-order tree and what derives from it: built once, whatever the number of devices
   int rc = prepare_scene(*d, prep, err);
@@ -413,8 +443,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   if (s->pipeline < RTX_PIPELINE_AUTO || s->pipeline > RTX_PIPELINE_WAVEFRONT) return fail(RTX_ERR_INVALID_ARGUMENT, "pipeline %d", s->pipeline);
   if (s->mode != RTX_MODE_WHITTED && s->mode != RTX_MODE_PATHTRACE && s->mode != RTX_MODE_BDPT && s->mode != RTX_MODE_PATHPHOTON)
     return fail(RTX_ERR_UNSUPPORTED, "render mode %d: only Whitted (0), PathTrace (1), BDPT (2) and PathPhoton (6) are implemented", s->mode);
-  if (s->mode == RTX_MODE_PATHPHOTON && (s->photon_gather_count < 1 || s->photon_gather_count > kPhotonMaxGather))
-    return fail(RTX_ERR_UNSUPPORTED, "photon_gather_count %d: 1 to %d are implemented", s->photon_gather_count, kPhotonMaxGather);
+  if (s->mode == RTX_MODE_PATHPHOTON && s->photon_gather_count < 1) return fail(RTX_ERR_INVALID_ARGUMENT, "photon_gather_count %d", s->photon_gather_count);
   if (s->mode == RTX_MODE_PATHPHOTON && !(s->caustic_gather_radius >= 0.0f)) return fail(RTX_ERR_INVALID_ARGUMENT, "caustic_gather_radius %g", (double)s->caustic_gather_radius);
   if (s->mode == RTX_MODE_BDPT && !(s->clamp_max == s->clamp_max)) return fail(RTX_ERR_INVALID_ARGUMENT, "clamp_max is NaN");
   if (s->rng < RTX_RNG_AUTO || s->rng > RTX_RNG_PCG4D) return fail(RTX_ERR_INVALID_ARGUMENT, "rng %d", s->rng);
@@ -483,6 +512,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   }
 
   const bool needs_stack = c->scene.n_prims > kLinearMaxPrims;
+  bool photon_map_reused = false;
   if (!photon) HIP_TRY(hipEventRecord(c->ev0, stream));   // PathPhoton records it behind its photon pass
   if (pipeline == RTX_PIPELINE_FUSED) {
     const size_t elem = f64 ? sizeof(double) : sizeof(float);
@@ -519,9 +549,21 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
       // its tree there), so its traversal stacks are sized from the scene alone
       const size_t walk_lds = stack_words(c, f64) * kBlock * sizeof(int);
       const auto ph0 = std::chrono::steady_clock::now();
-      const int prc = f64 ? photon_pass(c, s, P, c->scene.dev_d, walk_lds, stream) : photon_pass(c, s, P, c->scene.dev_f, walk_lds, stream);
+      const int prc = f64 ? photon_pass(c, s, P, c->scene.dev_d, walk_lds, stream, photon_map_reused) : photon_pass(c, s, P, c->scene.dev_f, walk_lds, stream, photon_map_reused);
       if (prc != RTX_OK) return prc;
       st.seconds_photon_pass = std::chrono::duration<double>(std::chrono::steady_clock::now() - ph0).count();
+      // An estimate keeps min(photon_gather_count, photons stored) photons.  Up to kPhotonMaxGather the candidate list of a wave
+      // sits in LDS; beyond, every wave of the grid gets two lists in device memory, and the grid shrinks if they would pass 2 GiB.
+      const long long keep = std::min<long long>(s->photon_gather_count, P.n_photons);
+      if (keep > kPhotonMaxGather) {
+        const unsigned long long cap = ((unsigned long long)keep + 63ull) / 64ull * 64ull + 128ull;
+        const unsigned long long per_block = (unsigned long long)(kBlock / 64) * cap * 2ull * (elem + sizeof(int));
+        const unsigned long long max_blocks = (2ull << 30) / per_block;
+        if (max_blocks < 1) return fail(RTX_ERR_OUT_OF_MEMORY, "photon_gather_count %d: the candidate lists of one workgroup need %llu bytes", s->photon_gather_count, per_block);
+        if ((unsigned long long)L.grid > max_blocks) L.grid = (int)max_blocks;
+        if (!c->ph_cand.ensure((size_t)(per_block * (unsigned long long)L.grid))) return fail(RTX_ERR_OUT_OF_MEMORY, "photon candidate lists (%llu bytes)", per_block * (unsigned long long)L.grid);
+        P.ph_cand = c->ph_cand.ptr; P.ph_cand_cap = (int32_t)cap;
+      }
       HIP_TRY(hipEventRecord(c->ev0, stream));
     }
     if (bdpt) {
@@ -564,6 +606,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   st.samples = hc.samples; st.rays_closest = hc.closest; st.rays_shadow = hc.shadow; st.segments = hc.segments;
+  if (photon_map_reused) st.rays_closest += c->ph_map.closest;   // the queries this film's photon map was traced with, made by an earlier call
   st.nodes_visited = hc.nodes_visited; st.prims_tested = hc.prims_tested;
   if (pipeline == RTX_PIPELINE_WAVEFRONT) st.seconds_extend = c->wf.timed_seconds();
   st.seconds_render = ms * 1e-3;

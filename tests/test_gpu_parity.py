@@ -242,6 +242,8 @@ def test_bdpt_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
                                                         ("textured", 1, 3000, 100, 0.5), ("normal_mapped", 1, 3000, 30, 0.3), ("cornell_box_quad", 1, 2000, 20, 0.2),
                                                         ("cornell_box", 1, 60000, 50, 0.15),   # enough photons for a kd-tree several levels deep above the GPU's buckets
                                                         ("cornell_box", 1, 90000, 40, 0.12),   # not walked, and more bounding boxes than the GPU keeps in LDS
+                                                        ("cornell_box", 1, 4000, 300, 0.5),     # more photons per estimate than a wave's LDS list holds: lists in device memory
+                                                        ("cornell_box", 1, 2500, 100000, 0.45), # more than there are photons: every photon in reach is kept
                                                         ("soup_box", 1, 3000, 30, 0.3),         # cornell_box + 600 triangles: the instances that walk a BVH with an LDS stack
                                                         ("sphere_field", 1, 3000, 30, 0.3)])    # 14 spheres: flat render kernel, but the photon pass walks the tree (LDS stack sized from the scene)
 def test_pathphoton_film_equals_oracle(name, nee, photons, k, radius, pkg, oracle, tracer, load_scene, monkeypatch):
@@ -290,7 +292,11 @@ def test_pathphoton_film_equals_oracle(name, nee, photons, k, radius, pkg, oracl
         bad = (np.abs(f32 - ref32) > 2e-3 * (1.0 + np.abs(ref32))).any(axis=2)
         record_rate("pathphoton_f32_bad_pixels_" + name + f"_{photons}", rate=float(bad.mean()))
         assert bad.mean() < PATHPHOTON_F32_BAD_PIXELS_MAX, (bad.mean(), np.abs(f32 - ref32).max())
-    pt.set_settings(sd.settings(photon_gather_count=129, **{k_: v for k_, v in over.items() if k_ != "photon_gather_count"}))
+    # the same render again: the context reuses its photon map (nothing to trace or build) and returns the same film and counts
+    again = pt.render().astype(np.float64)
+    s_again = pt.last_stats
+    assert np.array_equal(again, f32) and s_again.rays_closest == s32.rays_closest and s_again.seconds_photon_pass <= s32.seconds_photon_pass
+    pt.set_settings(sd.settings(photon_gather_count=0, **{k_: v for k_, v in over.items() if k_ != "photon_gather_count"}))
     with pytest.raises(pkg.abi.RtxError, match="photon_gather_count"):
         pt.render()
 
