@@ -1251,12 +1251,22 @@ RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, Hit<R>& rec,
   // `return` here hipcc 7.2 -O2/-O3 emitted, in one instantiation, code that gave the SURVIVING
   // lanes the old ray.d.y/z (the copy meant for terminated lanes ran for every lane of the branch).
   bool killed = false;
+#ifdef RTX_RR_EARLY_RETURN
+  // The early-return form, compiled only into the toolchain-guard library (make guard; tests/test_gpu_toolchain_guard.py
+  // renders with it and reports whether the compiler still gets it wrong).  Never part of librtx_hip.so.
+  if (bounce > 3) {
+    R p = max_(ps.thr.x, max_(ps.thr.y, ps.thr.z));
+    if (p < R(0.01) || u16lo<R>(rn.z) > p) { ps.bounce_flags = 0; return did; }
+    ps.thr = ps.thr * (R(1) / p);
+  }
+#else
   if (bounce > 3) {
     R p = max_(ps.thr.x, max_(ps.thr.y, ps.thr.z));
     killed = p < R(0.01) || u16lo<R>(rn.z) > p;
     R boost = killed ? R(1) : R(1) / p;
     ps.thr = ps.thr * boost;
   }
+#endif
   ps.ray.o = rec.p;
   ps.ray.d = sdir;
   ps.bsdf_pdf = bsdf_pdf;

@@ -23,10 +23,10 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("prim_type", "<i4"), ("prim_index", "<i4"
 
 
 class HipPathTracer:
-    def __init__(self, device_id: int = 0, device_ids: list[int] | None = None):
+    def __init__(self, device_id: int = 0, device_ids: list[int] | None = None, lib=None):
         """One GPU (`device_id`, as GPUPathTracer), or with `device_ids` one context over several GPUs of the node
         (rtx_create_multi): same methods, the rows of the film dealt to the devices and gathered on device_ids[0]."""
-        self._lib = abi.load_library()
+        self._lib = lib if lib is not None else abi.load_library()   # `lib`: another build of the library (abi.load_library(path)), for tests
         self._ctx = C.c_void_p()
         if device_ids is None:
             abi.check(self._lib, self._lib.rtx_create(C.byref(self._ctx), device_id), "rtx_create")
