@@ -30,7 +30,8 @@
 namespace rtx {
 namespace {
 
-struct BuildCounters { uint32_t nodes, leaves; uint32_t cmin[3], cmax[3]; };   // centroid bounds as order-preserving integers
+struct BuildCounters { uint32_t nodes, leaves; uint32_t cmin[3], cmax[3], bmin[3], bmax[3]; };   // centroid bounds and primitive bounds as order-preserving integers
+struct OriginGrid { float anchor[3], step[3]; };   // the grid node origins are stored on (DNode8::org)
 struct NodeMeta { int32_t inner_base, leaf_base; int32_t n_inner, n_leaf; };
 
 __device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
@@ -67,13 +68,19 @@ __global__ __launch_bounds__(256) void prim_box_kernel(const DSphere<float>* __r
     lo4[p] = make_float4(lo[0], lo[1], lo[2], 0.f);
     hi4[p] = make_float4(hi[0], hi[1], hi[2], 0.f);
   }
-  float cmin[3], cmax[3];
-  for (int a = 0; a < 3; ++a) { const float c = 0.5f * lo[a] + 0.5f * hi[a]; cmin[a] = valid ? c : kBig; cmax[a] = valid ? c : -kBig; }
+  float cmin[3], cmax[3], bmin[3], bmax[3];
+  for (int a = 0; a < 3; ++a) { const float c = 0.5f * lo[a] + 0.5f * hi[a]; cmin[a] = valid ? c : kBig; cmax[a] = valid ? c : -kBig; bmin[a] = lo[a]; bmax[a] = hi[a]; }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
-    for (int a = 0; a < 3; ++a) { cmin[a] = fminf(cmin[a], __shfl_xor(cmin[a], off, 64)); cmax[a] = fmaxf(cmax[a], __shfl_xor(cmax[a], off, 64)); }
+    for (int a = 0; a < 3; ++a) {
+      cmin[a] = fminf(cmin[a], __shfl_xor(cmin[a], off, 64)); cmax[a] = fmaxf(cmax[a], __shfl_xor(cmax[a], off, 64));
+      bmin[a] = fminf(bmin[a], __shfl_xor(bmin[a], off, 64)); bmax[a] = fmaxf(bmax[a], __shfl_xor(bmax[a], off, 64));
+    }
   if ((threadIdx.x & 63) == 0 && cmin[0] <= cmax[0])
-    for (int a = 0; a < 3; ++a) { atomicMin(&ctr->cmin[a], f2ord(cmin[a])); atomicMax(&ctr->cmax[a], f2ord(cmax[a])); }
+    for (int a = 0; a < 3; ++a) {
+      atomicMin(&ctr->cmin[a], f2ord(cmin[a])); atomicMax(&ctr->cmax[a], f2ord(cmax[a]));
+      atomicMin(&ctr->bmin[a], f2ord(bmin[a])); atomicMax(&ctr->bmax[a], f2ord(bmax[a]));
+    }
 }
 
 __device__ __forceinline__ uint64_t spread21(uint32_t v) {
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) void split_level_kernel(const uint64_t* __rest
 __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, const NodeMeta* __restrict__ meta, const int2* __restrict__ leaf_range,
                                                          const uint32_t* __restrict__ order, const float4* __restrict__ plo, const float4* __restrict__ phi,
                                                          float4* nlo, float4* nhi, DNode8* __restrict__ nodes, DLeaf3* __restrict__ leaves,
-                                                         const DTri<float>* __restrict__ tris, int ns, int nt) {
+                                                         const DTri<float>* __restrict__ tris, int ns, int nt, OriginGrid grid) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = g & 7;
   const bool active = (g >> 3) < count;
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, c
           rec.other |= 1u << k;
         }
       }
-      leaves[l] = rec;
+      leaves[(size_t)8 * node + (s - m.n_inner)] = rec;   // the node's own eight leaf slots
     }
   }
   float lo[3], hi[3];
@@ -201,18 +208,29 @@ __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, c
   const bool node_empty = !(lo[0] <= hi[0]);
   DNode8& out = nodes[node];
   uint32_t exps = 0u;
+  uint32_t ou[3] = {0u, 0u, 0u};
   for (int a = 0; a < 3; ++a) {
-    // unit 2^e with 255 units covering the extent; the loop settles what rounding leaves open
+    // the origin: the grid point at or below the node's lower corner, evaluated as the traversal kernels evaluate it
+    float org = grid.anchor[a];
+    if (!node_empty && grid.step[a] > 0.f) {
+      double u = floor(((double)lo[a] - (double)grid.anchor[a]) / (double)grid.step[a]);
+      const double top = (double)((1u << kNodeOriginBits) - 1u);
+      u = u < 0.0 ? 0.0 : (u > top ? top : u);
+      ou[a] = (uint32_t)u;
+      while (ou[a] > 0u && fmaf((float)ou[a], grid.step[a], grid.anchor[a]) > lo[a]) --ou[a];   // what rounding leaves open
+      org = fmaf((float)ou[a], grid.step[a], grid.anchor[a]);
+    }
+    // unit 2^e with 255 units covering the extent above the origin; the loop settles what rounding leaves open
     int e = -126;
-    const double ext = node_empty ? 0.0 : (double)hi[a] - (double)lo[a];
+    const double ext = node_empty ? 0.0 : (double)hi[a] - (double)org;
     if (ext > 0.0) { (void)frexp(ext / 255.0, &e); if (e < -126) e = -126; }
     while (e < 127 && ceil(ext / ldexp(1.0, e)) > 255.0) ++e;
     exps |= (uint32_t)(e + 127) << (8 * a);
     const double inv_unit = ldexp(1.0, -e);
-    int ql = 0, qh = 0;   // an unused slot (never tested) or a child without a hittable primitive (a point: its leaf holds NaN vertices)
+    int ql = 255, qh = 0;   // an unused slot, or a child without a hittable primitive: upper plane below lower plane, entered by no ray
     if (!node_empty && clo[0] <= chi[0]) {
-      ql = (int)floor(((double)clo[a] - (double)lo[a]) * inv_unit);
-      qh = (int)ceil(((double)chi[a] - (double)lo[a]) * inv_unit);
+      ql = (int)floor(((double)clo[a] - (double)org) * inv_unit);
+      qh = (int)ceil(((double)chi[a] - (double)org) * inv_unit);
       ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql); qh = qh > 255 ? 255 : (qh < 0 ? 0 : qh);
     }
     reinterpret_cast<uint8_t*>(out.qlo[a])[s] = (uint8_t)ql;
@@ -221,10 +239,11 @@ __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, c
   if (s == 0) {
     nlo[node] = node_empty ? make_float4(kBig, kBig, kBig, 0.f) : make_float4(lo[0], lo[1], lo[2], 0.f);
     nhi[node] = node_empty ? make_float4(-kBig, -kBig, -kBig, 0.f) : make_float4(hi[0], hi[1], hi[2], 0.f);
-    for (int a = 0; a < 3; ++a) out.org[a] = node_empty ? 0.f : lo[a];
+    out.org[0] = ou[0] | (ou[1] << 21);
+    out.org[1] = (ou[1] >> 11) | (ou[2] << 10);
     const int n_child = m.n_inner + m.n_leaf;
     out.exps = exps | ((uint32_t)m.n_inner << 24) | ((uint32_t)(n_child - 1) << 28);
-    out.inner_base = m.inner_base; out.leaf_base = m.leaf_base;
+    out.inner_base = m.inner_base;
   }
 }
 
@@ -257,7 +276,7 @@ int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& ou
       !ctr.alloc(sizeof(BuildCounters))) { err = "tree build: temporary buffers"; return RTX_ERR_OUT_OF_MEMORY; }
   BuildCounters hc;
   hc.nodes = 1u; hc.leaves = 0u;
-  for (int a = 0; a < 3; ++a) { hc.cmin[a] = 0xffffffffu; hc.cmax[a] = 0u; }
+  for (int a = 0; a < 3; ++a) { hc.cmin[a] = 0xffffffffu; hc.cmax[a] = 0u; hc.bmin[a] = 0xffffffffu; hc.bmax[a] = 0u; }
   BUILD_TRY(hipMemcpyAsync(ctr.p, &hc, sizeof hc, hipMemcpyHostToDevice, stream));
   hipLaunchKernelGGL(prim_box_kernel, dim3(grid), dim3(256), 0, stream, sc.spheres, ns, sc.tris, nt, sc.boxes, nb, d_dead, lo4.as<float4>(), hi4.as<float4>(),
                      ctr.as<BuildCounters>());
@@ -285,13 +304,25 @@ int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& ou
     if (level_first.size() > 200) { err = "tree build: too many levels"; return RTX_ERR_HIP; }
   }
   const int n_nodes = (int)hc.nodes, n_leaves = (int)hc.leaves, levels = (int)level_first.size() - 1;
-  if (!out.nodes.ensure((size_t)n_nodes * sizeof(DNode8)) || !out.leaves.ensure((size_t)(n_leaves ? n_leaves : 1) * sizeof(DLeaf3)) || !nlo.alloc((size_t)n_nodes * 16) ||
+  // every node owns eight leaf slots (DNode8): the slots of nodes without leaves are never touched
+  if (!out.nodes.ensure((size_t)n_nodes * sizeof(DNode8)) || !out.leaves.ensure((size_t)n_nodes * 8 * sizeof(DLeaf3)) || !nlo.alloc((size_t)n_nodes * 16) ||
       !nhi.alloc((size_t)n_nodes * 16)) { err = "tree build: node and leaf records"; return RTX_ERR_OUT_OF_MEMORY; }
   BUILD_TRY(hipMemsetAsync(out.nodes.ptr, 0, (size_t)n_nodes * sizeof(DNode8), stream));
+  // (an all-zero leaf record holds three degenerate triangles and no other primitive: nothing to hit, should a slot that was
+  // never written ever be read)
+  BUILD_TRY(hipMemsetAsync(out.leaves.ptr, 0, (size_t)n_nodes * 8 * sizeof(DLeaf3), stream));
+  OriginGrid og;   // hc holds the primitive bounds since the first level's read-back
+  for (int a = 0; a < 3; ++a) {
+    const bool any = hc.bmin[a] <= hc.bmax[a] && hc.bmin[a] != 0xffffffffu;
+    const float mn = any ? ord2f(hc.bmin[a]) : 0.f, mx = any ? ord2f(hc.bmax[a]) : 0.f;
+    og.anchor[a] = mn;
+    og.step[a] = mx > mn ? (float)(((double)mx - (double)mn) / (double)(1u << kNodeOriginBits)) : 0.f;
+    out.anchor[a] = og.anchor[a]; out.step[a] = og.step[a];
+  }
   for (int L = levels - 1; L >= 0; --L) {
     const int f = level_first[(size_t)L], c = level_first[(size_t)L + 1] - f;
     hipLaunchKernelGGL(emit_level_kernel, dim3((unsigned)(((size_t)c * 8 + 255) / 256)), dim3(256), 0, stream, f, c, meta.as<NodeMeta>(), leaf_range.as<int2>(), order,
-                       lo4.as<float4>(), hi4.as<float4>(), nlo.as<float4>(), nhi.as<float4>(), (DNode8*)out.nodes.ptr, (DLeaf3*)out.leaves.ptr, sc.tris, ns, nt);
+                       lo4.as<float4>(), hi4.as<float4>(), nlo.as<float4>(), nhi.as<float4>(), (DNode8*)out.nodes.ptr, (DLeaf3*)out.leaves.ptr, sc.tris, ns, nt, og);
   }
   BUILD_TRY(hipGetLastError());
   float4 root_lo, root_hi;

@@ -391,7 +391,7 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
 // ------------------------------------------------------------------------------------------
 // Single-precision walk over the eight-wide tree (DNode8 / DLeaf3, pt_types.hpp), cut into resumable steps so that the
 // lanes of a persistent kernel can pick up a new ray when theirs is finished.
-//   walk8_inner  fetches ONE node record (a 128-byte line), tests its eight quantised boxes, continues with the nearest
+//   walk8_inner  fetches ONE node record (64 bytes), tests its eight quantised boxes, continues with the nearest
 //                child entered and parks the others, nearest first, as ONE stack entry;
 //   walk8_leaf   fetches ONE leaf record (a 128-byte line) and tests its up to three triangles (spheres and boxes through
 //                their tables).
@@ -432,29 +432,35 @@ RTX_DEV int walk8_pop(Walk8& w, LaneStack st) {
 RTX_DEV void walk8_inner(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_best, Walk8& w, LaneStack st) {
   const uint4* rec = reinterpret_cast<const uint4*>(sc.nodes8 + w.node);
   const uint4 h0 = rec[0], h1 = rec[1], h2 = rec[2], h3 = rec[3];
-  const uint2 h4 = *reinterpret_cast<const uint2*>(rec + 4);
-  const uint32_t exps = h0.w;
+  const uint32_t exps = h0.z;
+  // the node's origin: a point of the scene's 2^21-step grid
+  const float ox = fmaf((float)(h0.x & 0x1fffffu), sc.wt_step[0], sc.wt_anchor[0]);
+  const float oy = fmaf((float)((h0.x >> 21) | ((h0.y & 0x3ffu) << 11)), sc.wt_step[1], sc.wt_anchor[1]);
+  const float oz = fmaf((float)((h0.y >> 10) & 0x1fffffu), sc.wt_step[2], sc.wt_anchor[2]);
   // slab distance of a quantised plane q:  (org + q * unit - o) / d  =  q * (unit / d) + (org - o) / d
   const float ax = __uint_as_float((exps & 0xffu) << 23) * w.inv.x, ay = __uint_as_float(((exps >> 8) & 0xffu) << 23) * w.inv.y,
               az = __uint_as_float(((exps >> 16) & 0xffu) << 23) * w.inv.z;
-  const float bx = (__uint_as_float(h0.x) - r.o.x) * w.inv.x, by = (__uint_as_float(h0.y) - r.o.y) * w.inv.y, bz = (__uint_as_float(h0.z) - r.o.z) * w.inv.z;
-  const uint32_t qlx[2] = {h1.x, h1.y}, qly[2] = {h1.z, h1.w}, qlz[2] = {h2.x, h2.y};
-  const uint32_t qhx[2] = {h2.z, h2.w}, qhy[2] = {h3.x, h3.y}, qhz[2] = {h3.z, h3.w};
-  const int n_inner = (int)((exps >> 24) & 15u), n_child = (int)(exps >> 28) + 1;
-  const int inner_base = (int)h4.x, leaf_base = (int)h4.y - n_inner;   // child k >= n_inner is leaf leaf_base + k
+  const float bx = (ox - r.o.x) * w.inv.x, by = (oy - r.o.y) * w.inv.y, bz = (oz - r.o.z) * w.inv.z;
+  // The ray enters a slab through its lower plane when it travels up the axis, through its upper plane otherwise: which of
+  // the two plane sets is "near" is chosen once per node and axis (the planes of a child are ordered, lower <= upper, so this is
+  // min / max of the two distances without computing them per child).  An unused slot holds planes (255, 0): its far distance
+  // lies before its near one on every axis, no ray enters it.
+  const bool ux = w.inv.x >= 0.f, uy = w.inv.y >= 0.f, uz = w.inv.z >= 0.f;
+  const uint32_t nx[2] = {ux ? h1.x : h2.z, ux ? h1.y : h2.w}, fx[2] = {ux ? h2.z : h1.x, ux ? h2.w : h1.y};
+  const uint32_t ny[2] = {uy ? h1.z : h3.x, uy ? h1.w : h3.y}, fy[2] = {uy ? h3.x : h1.z, uy ? h3.y : h1.w};
+  const uint32_t nz[2] = {uz ? h2.x : h3.z, uz ? h2.y : h3.w}, fz[2] = {uz ? h3.z : h2.x, uz ? h3.w : h2.y};
+  const int n_inner = (int)((exps >> 24) & 15u);
+  const int inner_base = (int)h0.w, leaf_base = 8 * w.node - n_inner;   // child k >= n_inner is leaf record leaf_base + k: the node's own eight leaf slots
   uint32_t key[8];
   int m = 0;   // children entered
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int sh = 8 * (k & 3);
-    float t0 = fmaf((float)((qlx[k >> 2] >> sh) & 0xffu), ax, bx), t1 = fmaf((float)((qhx[k >> 2] >> sh) & 0xffu), ax, bx);
-    float a = fminf(t0, t1), b = fmaxf(t0, t1);
-    t0 = fmaf((float)((qly[k >> 2] >> sh) & 0xffu), ay, by); t1 = fmaf((float)((qhy[k >> 2] >> sh) & 0xffu), ay, by);
-    a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
-    t0 = fmaf((float)((qlz[k >> 2] >> sh) & 0xffu), az, bz); t1 = fmaf((float)((qhz[k >> 2] >> sh) & 0xffu), az, bz);
-    a = fmaxf(a, fminf(t0, t1)); b = fminf(b, fmaxf(t0, t1));
-    a = fmaxf(a, t_min); b = fminf(b, t_best);
-    const bool ok = a <= b && k < n_child;   // (an unused slot's planes (255, 0) read as the whole node under min / max)
+    const float a = fmaxf(fmaxf(fmaf((float)((nx[k >> 2] >> sh) & 0xffu), ax, bx), fmaf((float)((ny[k >> 2] >> sh) & 0xffu), ay, by)),
+                          fmaxf(fmaf((float)((nz[k >> 2] >> sh) & 0xffu), az, bz), t_min));
+    const float b = fminf(fminf(fmaf((float)((fx[k >> 2] >> sh) & 0xffu), ax, bx), fmaf((float)((fy[k >> 2] >> sh) & 0xffu), ay, by)),
+                          fminf(fmaf((float)((fz[k >> 2] >> sh) & 0xffu), az, bz), t_best));
+    const bool ok = a <= b;
     // sortable key: the entry distance (a positive float, whose bit pattern orders as an unsigned integer) with the slot in
     // its three lowest bits
     key[k] = ok ? ((__float_as_uint(a) & ~7u) | (uint32_t)k) : 0xffffffffu;

@@ -44,8 +44,9 @@ struct HostBvh {
 // The eight-wide tree of the single-precision kernels, built on the GPU (bvh_build.hip).
 struct WideTree {
   DeviceBuffer nodes, leaves;   // DNode8 / DLeaf3 records
-  int n_nodes = 0, n_leaves = 0, levels = 0;
+  int n_nodes = 0, n_leaves = 0, levels = 0;   // n_leaves: leaf records in use (the array holds 8 per node)
   float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};   // the root's box
+  float anchor[3] = {0.f, 0.f, 0.f}, step[3] = {0.f, 0.f, 0.f};   // grid of the node origins (DScene::wt_anchor, wt_step)
   double seconds = 0.0;         // device + host time of the build
   void release() { nodes.release(); leaves.release(); n_nodes = n_leaves = levels = 0; }
 };

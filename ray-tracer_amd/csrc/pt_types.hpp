@@ -39,18 +39,23 @@ template <class R> struct DNode2 { R lo[3], hi[3]; int32_t a, count; };
 // decides which primitives can be hit at all (a primitive whose reference leaf box is flat along an axis is never reached
 // there and is built into this tree as unhittable).
 //
-// One node record is one 128-byte line: the boxes of up to eight children as 8-bit offsets from the node's own origin in
-// units of 2^e per axis, rounded outward (Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs Through
-// Compressed Wide BVHs", HPG 2017).  Children 0 .. n_inner-1 are the nodes inner_base + k, children n_inner .. n_child-1 the
-// leaf records leaf_base + (k - n_inner); unused slots hold an inverted box (255, 0) that no ray enters.
-struct alignas(128) DNode8 {
-  float org[3];
+// One node record is 64 bytes, four 16-byte loads: the boxes of up to eight children as 8-bit offsets from the node's own origin
+// in units of 2^e per axis, rounded outward (Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs Through
+// Compressed Wide BVHs", HPG 2017).  The origin is itself a point of a 2^21-step grid over the scene's bounds
+// (DScene::wt_anchor + u * DScene::wt_step per axis, evaluated with one fmaf exactly as the builder evaluated it), three 21-bit
+// numbers in two words.  Children 0 .. n_inner-1 are the nodes inner_base + k; children n_inner .. n_child-1 are leaf records,
+// and the leaves of node i are the records 8 i, 8 i + 1, ... of the leaf array (eight slots reserved per node: most nodes that
+// have leaves have eight, and the address needs no word in the record).  Unused slots hold planes (255, 0), an interval no ray enters
+// (the traversal picks near and far planes by the ray's direction, it does not order them).
+struct alignas(64) DNode8 {
+  uint32_t org[2];        // x: bits 0-20 of org[0]; y: bits 21-31 of org[0] (low 11) and bits 0-9 of org[1] (high 10); z: bits 10-30 of org[1]
   uint32_t exps;          // byte a (0..2): biased float exponent of axis a's unit; bits 24-27: n_inner; bits 28-31: n_child - 1
+  int32_t inner_base;
   uint32_t qlo[3][2];     // byte (k & 3) of qlo[a][k >> 2]: child k's lower plane on axis a
   uint32_t qhi[3][2];
-  int32_t inner_base, leaf_base;
-  uint32_t pad[14];
 };
+static_assert(sizeof(DNode8) == 64, "node record");
+constexpr int kNodeOriginBits = 21;
 // One leaf record is one 128-byte line: up to three triangles with their vertices in place.  id = the primitive's number in
 // the reference's primitive list (spheres, then triangles, then boxes: engine/scene.hpp:496-533), -1 for an empty slot.  A
 // slot that holds a sphere or a box (bit k of `other`) or nothing has NaN vertices, which fail the triangle test.
@@ -92,6 +97,7 @@ template <class R> struct DScene {
   const int32_t* rank;                                 // position of every bounded primitive (numbered as DLeaf3::id) in the reference's leaf order
   const DFlatRec* flat;                                // flat scenes only (single precision)
   float bb_lo[3], bb_scale[3];                         // the eight-wide tree's root box as a 128^3 grid: cell = (p - bb_lo) * bb_scale (ray sorting)
+  float wt_anchor[3], wt_step[3];                      // the grid the node origins of the eight-wide tree lie on (DNode8::org)
   int32_t n_spheres, n_planes, n_tris, n_boxes, n_points, n_quads, n_disks, n_mats, n_images, n_emissive;
   int32_t n_nodes, n_prims, n_nodes8, n_leaves3, walk_levels;
   int32_t n_nmaps;                                     // materials with a normal map (picks the kernel instances that apply them)
