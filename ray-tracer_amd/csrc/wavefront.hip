@@ -49,9 +49,11 @@ struct WfArrays {
 
 struct WfControl { uint32_t n_q[2]; uint32_t n_shadow; uint32_t cursor; };   // cursor: next queue entry a persistent kernel hands out
 
-// A persistent traversal wave runs the leaf phase when at least this many lanes have a leaf pending.
+// A persistent traversal wave runs the leaf phase when at least this many lanes have a leaf pending (or none has a node).
+// A leaf phase costs about as many instructions as a node phase and, one leaf per four nodes, serves a fifth of the lanes:
+// measured on the 10 M-triangle scene (closest-hit kernel, 64 spp): 2: 299 ms, 8: 290, 16: 289, 24: 296.
 #ifndef RTX_LEAF_BATCH
-#define RTX_LEAF_BATCH 2
+#define RTX_LEAF_BATCH 8
 #endif
 constexpr int kLeafBatch = RTX_LEAF_BATCH;
 
