@@ -30,9 +30,9 @@
 namespace rtx {
 namespace {
 
-struct BuildCounters { uint32_t nodes, leaves; uint32_t cmin[3], cmax[3], bmin[3], bmax[3]; };   // centroid bounds and primitive bounds as order-preserving integers
+struct BuildCounters { uint32_t nodes, leaves, units; uint32_t cmin[3], cmax[3], bmin[3], bmax[3]; };   // centroid bounds and primitive bounds as order-preserving integers
 struct OriginGrid { float anchor[3], step[3]; };   // the grid node origins are stored on (DNode8::org)
-struct NodeMeta { int32_t inner_base, leaf_base; int32_t n_inner, n_leaf; };
+struct NodeMeta { int32_t inner_base, leaf_base; int32_t n_inner, n_leaf; int32_t unit_base, pad; };   // unit_base: where the children's records start, in 64-byte units
 
 __device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __host__ __device__ inline float ord2f(uint32_t u) {
@@ -128,7 +128,7 @@ __device__ __forceinline__ int find_split(const uint64_t* __restrict__ codes, in
 }
 
 __global__ __launch_bounds__(256) void split_level_kernel(const uint64_t* __restrict__ codes, int2* range, NodeMeta* __restrict__ meta, int2* __restrict__ leaf_range,
-                                                          int first, int count, BuildCounters* ctr) {
+                                                          int32_t* __restrict__ unit_of, int first, int count, BuildCounters* ctr) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count) return;
   const int node = first + t;
@@ -151,20 +151,23 @@ __global__ __launch_bounds__(256) void split_level_kernel(const uint64_t* __rest
   const int n_leaf = n - n_inner;
   const int ib = n_inner ? (int)atomicAdd(&ctr->nodes, (uint32_t)n_inner) : 0;
   const int lb = n_leaf ? (int)atomicAdd(&ctr->leaves, (uint32_t)n_leaf) : 0;
+  // the children's records: the inner children's node records (one unit each), padded to an even count, then the leaf
+  // records (two units each): every block starts on an even unit, so that a leaf record is one 128-byte line
+  const int ub = (int)atomicAdd(&ctr->units, (uint32_t)(((n_inner + 1) & ~1) + 2 * n_leaf));
   int ki = 0, kl = 0;
   for (int i = 0; i < n; ++i) {
-    if (re[i] - rb[i] > kLeafMaxPrims) range[ib + ki++] = make_int2(rb[i], re[i]);
+    if (re[i] - rb[i] > kLeafMaxPrims) { unit_of[ib + ki] = ub + ki; range[ib + ki++] = make_int2(rb[i], re[i]); }
     else leaf_range[lb + kl++] = make_int2(rb[i], re[i] - rb[i]);
   }
   NodeMeta m;
-  m.inner_base = ib; m.leaf_base = lb; m.n_inner = n_inner; m.n_leaf = n_leaf;
+  m.inner_base = ib; m.leaf_base = lb; m.n_inner = n_inner; m.n_leaf = n_leaf; m.unit_base = ub; m.pad = 0;
   meta[node] = m;
 }
 
 // Eight lanes per node, one per child slot.
 __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, const NodeMeta* __restrict__ meta, const int2* __restrict__ leaf_range,
                                                          const uint32_t* __restrict__ order, const float4* __restrict__ plo, const float4* __restrict__ phi,
-                                                         float4* nlo, float4* nhi, DNode8* __restrict__ nodes, DLeaf3* __restrict__ leaves,
+                                                         float4* nlo, float4* nhi, DNode8* __restrict__ units, const int32_t* __restrict__ unit_of,
                                                          const DTri<float>* __restrict__ tris, int ns, int nt, OriginGrid grid) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = g & 7;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, c
           rec.other |= 1u << k;
         }
       }
-      leaves[(size_t)8 * node + (s - m.n_inner)] = rec;   // the node's own eight leaf slots
+      *reinterpret_cast<DLeaf3*>(units + m.unit_base + ((m.n_inner + 1) & ~1) + 2 * (s - m.n_inner)) = rec;
     }
   }
   float lo[3], hi[3];
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, c
     for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64)); }
   if (!active) return;
   const bool node_empty = !(lo[0] <= hi[0]);
-  DNode8& out = nodes[node];
+  DNode8& out = units[unit_of[node]];
   uint32_t exps = 0u;
   uint32_t ou[3] = {0u, 0u, 0u};
   for (int a = 0; a < 3; ++a) {
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, c
     out.org[1] = (ou[1] >> 11) | (ou[2] << 10);
     const int n_child = m.n_inner + m.n_leaf;
     out.exps = exps | ((uint32_t)m.n_inner << 24) | ((uint32_t)(n_child - 1) << 28);
-    out.inner_base = m.inner_base;
+    out.inner_base = m.unit_base;
   }
 }
 
@@ -270,12 +273,12 @@ int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& ou
   if (n <= 0) return RTX_OK;
   hipStream_t stream = nullptr;
   const unsigned grid = (unsigned)((n + 255) / 256);
-  Temp lo4, hi4, codes_a, codes_b, ids_a, ids_b, range, meta, leaf_range, ctr, sort_tmp, nlo, nhi;
+  Temp lo4, hi4, codes_a, codes_b, ids_a, ids_b, range, meta, leaf_range, unit_of, ctr, sort_tmp, nlo, nhi;
   if (!lo4.alloc((size_t)n * 16) || !hi4.alloc((size_t)n * 16) || !codes_a.alloc((size_t)n * 8) || !codes_b.alloc((size_t)n * 8) || !ids_a.alloc((size_t)n * 4) ||
       !ids_b.alloc((size_t)n * 4) || !range.alloc((size_t)n * 8) || !meta.alloc((size_t)n * sizeof(NodeMeta)) || !leaf_range.alloc((size_t)n * 8) ||
-      !ctr.alloc(sizeof(BuildCounters))) { err = "tree build: temporary buffers"; return RTX_ERR_OUT_OF_MEMORY; }
+      !unit_of.alloc((size_t)n * 4) || !ctr.alloc(sizeof(BuildCounters))) { err = "tree build: temporary buffers"; return RTX_ERR_OUT_OF_MEMORY; }
   BuildCounters hc;
-  hc.nodes = 1u; hc.leaves = 0u;
+  hc.nodes = 1u; hc.leaves = 0u; hc.units = 2u;   // the root's record is unit 0; unit 1 pads to an even start
   for (int a = 0; a < 3; ++a) { hc.cmin[a] = 0xffffffffu; hc.cmax[a] = 0u; hc.bmin[a] = 0xffffffffu; hc.bmax[a] = 0u; }
   BUILD_TRY(hipMemcpyAsync(ctr.p, &hc, sizeof hc, hipMemcpyHostToDevice, stream));
   hipLaunchKernelGGL(prim_box_kernel, dim3(grid), dim3(256), 0, stream, sc.spheres, ns, sc.tris, nt, sc.boxes, nb, d_dead, lo4.as<float4>(), hi4.as<float4>(),
@@ -291,11 +294,12 @@ int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& ou
   // top-down: level L's nodes are [level_first[L], level_first[L + 1])
   const int2 root = make_int2(0, n);
   BUILD_TRY(hipMemcpyAsync(range.p, &root, sizeof root, hipMemcpyHostToDevice, stream));
+  BUILD_TRY(hipMemsetAsync(unit_of.p, 0, 4, stream));
   std::vector<int> level_first{0};
   int first = 0, count = 1;
   while (count > 0) {
     hipLaunchKernelGGL(split_level_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, codes, range.as<int2>(), meta.as<NodeMeta>(),
-                       leaf_range.as<int2>(), first, count, ctr.as<BuildCounters>());
+                       leaf_range.as<int2>(), unit_of.as<int32_t>(), first, count, ctr.as<BuildCounters>());
     BUILD_TRY(hipMemcpyAsync(&hc, ctr.p, sizeof hc, hipMemcpyDeviceToHost, stream));
     BUILD_TRY(hipStreamSynchronize(stream));
     first += count;
@@ -304,13 +308,15 @@ int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& ou
     if (level_first.size() > 200) { err = "tree build: too many levels"; return RTX_ERR_HIP; }
   }
   const int n_nodes = (int)hc.nodes, n_leaves = (int)hc.leaves, levels = (int)level_first.size() - 1;
-  // every node owns eight leaf slots (DNode8): the slots of nodes without leaves are never touched
-  if (!out.nodes.ensure((size_t)n_nodes * sizeof(DNode8)) || !out.leaves.ensure((size_t)n_nodes * 8 * sizeof(DLeaf3)) || !nlo.alloc((size_t)n_nodes * 16) ||
-      !nhi.alloc((size_t)n_nodes * 16)) { err = "tree build: node and leaf records"; return RTX_ERR_OUT_OF_MEMORY; }
-  BUILD_TRY(hipMemsetAsync(out.nodes.ptr, 0, (size_t)n_nodes * sizeof(DNode8), stream));
-  // (an all-zero leaf record holds three degenerate triangles and no other primitive: nothing to hit, should a slot that was
-  // never written ever be read)
-  BUILD_TRY(hipMemsetAsync(out.leaves.ptr, 0, (size_t)n_nodes * 8 * sizeof(DLeaf3), stream));
+  // one array of 64-byte units holds the node records (one unit) and the leaf records (two units); eight spare leaf records of
+  // zeros behind it (three degenerate triangles each, nothing to hit): a node whose box is a single point cannot keep rays out
+  // of its unused slots, such a slot then reads a neighbouring record or one of these
+  const size_t n_units = (size_t)hc.units + 16;
+  if (n_units > 0x7fffffffull) { err = "tree build: more than 2^31 record units"; return RTX_ERR_UNSUPPORTED; }
+  if (!out.nodes.ensure(n_units * sizeof(DNode8)) || !nlo.alloc((size_t)n_nodes * 16) || !nhi.alloc((size_t)n_nodes * 16)) {
+    err = "tree build: node and leaf records"; return RTX_ERR_OUT_OF_MEMORY;
+  }
+  BUILD_TRY(hipMemsetAsync(out.nodes.ptr, 0, n_units * sizeof(DNode8), stream));
   OriginGrid og;   // hc holds the primitive bounds since the first level's read-back
   for (int a = 0; a < 3; ++a) {
     const bool any = hc.bmin[a] <= hc.bmax[a] && hc.bmin[a] != 0xffffffffu;
@@ -322,7 +328,7 @@ int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& ou
   for (int L = levels - 1; L >= 0; --L) {
     const int f = level_first[(size_t)L], c = level_first[(size_t)L + 1] - f;
     hipLaunchKernelGGL(emit_level_kernel, dim3((unsigned)(((size_t)c * 8 + 255) / 256)), dim3(256), 0, stream, f, c, meta.as<NodeMeta>(), leaf_range.as<int2>(), order,
-                       lo4.as<float4>(), hi4.as<float4>(), nlo.as<float4>(), nhi.as<float4>(), (DNode8*)out.nodes.ptr, (DLeaf3*)out.leaves.ptr, sc.tris, ns, nt, og);
+                       lo4.as<float4>(), hi4.as<float4>(), nlo.as<float4>(), nhi.as<float4>(), (DNode8*)out.nodes.ptr, unit_of.as<int32_t>(), sc.tris, ns, nt, og);
   }
   BUILD_TRY(hipGetLastError());
   float4 root_lo, root_hi;
@@ -330,7 +336,7 @@ int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& ou
   BUILD_TRY(hipMemcpyAsync(&root_hi, nhi.p, sizeof root_hi, hipMemcpyDeviceToHost, stream));
   BUILD_TRY(hipStreamSynchronize(stream));
   out.lo[0] = root_lo.x; out.lo[1] = root_lo.y; out.lo[2] = root_lo.z; out.hi[0] = root_hi.x; out.hi[1] = root_hi.y; out.hi[2] = root_hi.z;
-  out.n_nodes = n_nodes; out.n_leaves = n_leaves; out.levels = levels;
+  out.n_nodes = n_nodes; out.n_leaves = n_leaves; out.levels = levels; out.n_units = n_units;
   out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return RTX_OK;
 }

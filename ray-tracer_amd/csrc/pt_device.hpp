@@ -395,8 +395,8 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
 //                child entered and parks the others, nearest first, as ONE stack entry;
 //   walk8_leaf   fetches ONE leaf record (a 128-byte line) and tests its up to three triangles (spheres and boxes through
 //                their tables).
-// w.node is a node (>= 0), a leaf code ~leaf (< 0) or kWalkDone.  A stack entry is the group of siblings still to visit under
-// one node, three words: the node's inner_base, its leaf_base - n_inner, and  slots (3 bits each, next first) | remaining
+// w.node is a node record's unit (>= 0), a leaf code ~unit (< 0) or kWalkDone.  A stack entry is the group of siblings still to
+// visit under one node, three words: the node's inner_base, the unit its leaf records would start at if slot 0 were a leaf, and  slots (3 bits each, next first) | remaining
 // count << 24 | n_inner << 28;  a child's code follows from its slot.  One entry per level at most, so levels + 1 entries always
 // suffice.  A parked child is not re-tested against the interval the hits found meanwhile have shortened (its children /
 // primitives are).  A box is entered on a <= b: the tree's own grouping may make a box flat along an axis, which must not hide
@@ -426,7 +426,7 @@ RTX_DEV int walk8_pop(Walk8& w, LaneStack st) {
   const int slot = (int)(pk & 7u), cnt = (int)((pk >> 24) & 7u), ni = (int)(pk >> 28);
   if (cnt <= 1) --w.sp;
   else st.put(e + 2, (int)(((pk & 0x00ffffffu) >> 3) | ((uint32_t)(cnt - 1) << 24) | (pk & 0xf0000000u)));
-  return slot < ni ? ib + slot : ~(lb + slot);
+  return slot < ni ? ib + slot : ~(lb + 2 * slot);
 }
 
 RTX_DEV void walk8_inner(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_best, Walk8& w, LaneStack st) {
@@ -450,7 +450,7 @@ RTX_DEV void walk8_inner(const DScene<float>& sc, const Ray<float>& r, float t_m
   const uint32_t ny[2] = {uy ? h1.z : h3.x, uy ? h1.w : h3.y}, fy[2] = {uy ? h3.x : h1.z, uy ? h3.y : h1.w};
   const uint32_t nz[2] = {uz ? h2.x : h3.z, uz ? h2.y : h3.w}, fz[2] = {uz ? h3.z : h2.x, uz ? h3.w : h2.y};
   const int n_inner = (int)((exps >> 24) & 15u);
-  const int inner_base = (int)h0.w, leaf_base = 8 * w.node - n_inner;   // child k >= n_inner is leaf record leaf_base + k: the node's own eight leaf slots
+  const int inner_base = (int)h0.w, leaf_base = inner_base + ((n_inner + 1) & ~1) - 2 * n_inner;   // child k >= n_inner is the leaf record at unit leaf_base + 2 k
   uint32_t key[8];
   int m = 0;   // children entered
 #pragma unroll
@@ -483,7 +483,7 @@ RTX_DEV void walk8_inner(const DScene<float>& sc, const Ray<float>& r, float t_m
     st.put(e, inner_base); st.put(e + 1, leaf_base); st.put(e + 2, (int)(slots | ((uint32_t)(m - 1) << 24) | ((uint32_t)n_inner << 28)));
     ++w.sp;
   }
-  if (m >= 1) { const int k = (int)(key[0] & 7u); w.node = k < n_inner ? inner_base + k : ~(leaf_base + k); }
+  if (m >= 1) { const int k = (int)(key[0] & 7u); w.node = k < n_inner ? inner_base + k : ~(leaf_base + 2 * k); }
   else w.node = walk8_pop(w, st);
 }
 
@@ -503,7 +503,7 @@ RTX_DEV bool leaf_tri_t(const float* v, const Ray<float>& r, float t_min, float 
 }
 
 template <bool ANY> RTX_DEV void walk8_leaf(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, Walk8& w, LaneStack st) {
-  const DLeaf3* lf = sc.leaves3 + (~w.node);
+  const DLeaf3* lf = reinterpret_cast<const DLeaf3*>(sc.nodes8 + (~w.node));
   const uint4* rec = reinterpret_cast<const uint4*>(lf);
   uint4 q[8];
 #pragma unroll

@@ -43,12 +43,13 @@ struct HostBvh {
 
 // The eight-wide tree of the single-precision kernels, built on the GPU (bvh_build.hip).
 struct WideTree {
-  DeviceBuffer nodes, leaves;   // DNode8 / DLeaf3 records
-  int n_nodes = 0, n_leaves = 0, levels = 0;   // n_leaves: leaf records in use (the array holds 8 per node)
+  DeviceBuffer nodes;           // one array of 64-byte units: DNode8 records (one unit) and DLeaf3 records (two units, even-aligned)
+  size_t n_units = 0;
+  int n_nodes = 0, n_leaves = 0, levels = 0;
   float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};   // the root's box
   float anchor[3] = {0.f, 0.f, 0.f}, step[3] = {0.f, 0.f, 0.f};   // grid of the node origins (DScene::wt_anchor, wt_step)
   double seconds = 0.0;         // device + host time of the build
-  void release() { nodes.release(); leaves.release(); n_nodes = n_leaves = levels = 0; }
+  void release() { nodes.release(); n_nodes = n_leaves = levels = 0; n_units = 0; }
 };
 // `sc`: the single-precision scene with its primitive tables already on the device; `d_dead`: optional device array, one byte per
 // bounded primitive (numbered spheres, triangles, boxes), non-zero = the reference can never hit it (built in as unhittable).

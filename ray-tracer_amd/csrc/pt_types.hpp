@@ -43,10 +43,11 @@ template <class R> struct DNode2 { R lo[3], hi[3]; int32_t a, count; };
 // in units of 2^e per axis, rounded outward (Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs Through
 // Compressed Wide BVHs", HPG 2017).  The origin is itself a point of a 2^21-step grid over the scene's bounds
 // (DScene::wt_anchor + u * DScene::wt_step per axis, evaluated with one fmaf exactly as the builder evaluated it), three 21-bit
-// numbers in two words.  Children 0 .. n_inner-1 are the nodes inner_base + k; children n_inner .. n_child-1 are leaf records,
-// and the leaves of node i are the records 8 i, 8 i + 1, ... of the leaf array (eight slots reserved per node: most nodes that
-// have leaves have eight, and the address needs no word in the record).  Unused slots hold planes (255, 0), an interval no ray enters
-// (the traversal picks near and far planes by the ray's direction, it does not order them).
+// numbers in two words.  Node and leaf records share one array of 64-byte units.  The records of a node's children form one
+// block that starts at unit inner_base (an even unit): children 0 .. n_inner-1 are the node records inner_base + k; after
+// them, from the next even unit on, children n_inner .. n_child-1 are leaf records of two units each (128-byte aligned).
+// Unused slots hold planes (255, 0), an interval no ray enters (the traversal picks near and far planes by the ray's
+// direction, it does not order them).
 struct alignas(64) DNode8 {
   uint32_t org[2];        // x: bits 0-20 of org[0]; y: bits 21-31 of org[0] (low 11) and bits 0-9 of org[1] (high 10); z: bits 10-30 of org[1]
   uint32_t exps;          // byte a (0..2): biased float exponent of axis a's unit; bits 24-27: n_inner; bits 28-31: n_child - 1
@@ -93,7 +94,7 @@ template <class R> struct DScene {
   const DPoint<R>* points; const DQuad<R>* quads; const DDisk<R>* disks; const DMaterial<R>* mats;
   const DImage* images; const int32_t* emissive;   // indices of emissive spheres, ascending
   const DNode2<R>* nodes; const DPrimRef* prims;    // production BVH + primitive order (reference leaf order)
-  const DNode8* nodes8; const DLeaf3* leaves3;         // single-precision traversal layout (NULL in the double scene and for scenes tested linearly)
+  const DNode8* nodes8;                                // single-precision traversal layout: 64-byte units, node records and (two units each) leaf records (NULL in the double scene and for scenes tested linearly)
   const int32_t* rank;                                 // position of every bounded primitive (numbered as DLeaf3::id) in the reference's leaf order
   const DFlatRec* flat;                                // flat scenes only (single precision)
   float bb_lo[3], bb_scale[3];                         // the eight-wide tree's root box as a 128^3 grid: cell = (p - bb_lo) * bb_scale (ray sorting)
