@@ -429,7 +429,8 @@ RTX_DEV int walk8_pop(Walk8& w, LaneStack st) {
   return slot < ni ? ib + slot : ~(lb + 2 * slot);
 }
 
-RTX_DEV void walk8_inner(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_best, Walk8& w, LaneStack st) {
+// SORTED = false (any-hit queries): the children entered are visited in slot order, the sorting network is left out.
+template <bool SORTED = true> RTX_DEV void walk8_inner(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_best, Walk8& w, LaneStack st) {
   const uint4* rec = reinterpret_cast<const uint4*>(sc.nodes8 + w.node);
   const uint4 h0 = rec[0], h1 = rec[1], h2 = rec[2], h3 = rec[3];
   const uint32_t exps = h0.z;
@@ -465,6 +466,21 @@ RTX_DEV void walk8_inner(const DScene<float>& sc, const Ray<float>& r, float t_m
     // its three lowest bits
     key[k] = ok ? ((__float_as_uint(a) & ~7u) | (uint32_t)k) : 0xffffffffu;
     m += ok ? 1 : 0;
+  }
+  if constexpr (!SORTED) {
+    // slot order: the slots of the children entered, packed three bits each, lowest slot first
+    uint32_t slots = 0u;
+    int at = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const bool ok = key[k] != 0xffffffffu; slots |= ok ? ((uint32_t)k << at) : 0u; at += ok ? 3 : 0; }
+    if (m >= 2) {
+      const int e = 3 * w.sp;
+      st.put(e, inner_base); st.put(e + 1, leaf_base); st.put(e + 2, (int)((slots >> 3) | ((uint32_t)(m - 1) << 24) | ((uint32_t)n_inner << 28)));
+      ++w.sp;
+    }
+    if (m >= 1) { const int k = (int)(slots & 7u); w.node = k < n_inner ? inner_base + k : ~(leaf_base + 2 * k); }
+    else w.node = walk8_pop(w, st);
+    return;
   }
   // sorting network on the keys, ascending (19 compare-exchanges of one min and one max each)
 #define RTX_CX(i, j) { const uint32_t lo_ = umin_(key[i], key[j]); key[j] = umax_(key[i], key[j]); key[i] = lo_; }
@@ -544,7 +560,7 @@ template <bool ANY> RTX_DEV bool walk8(const DScene<float>& sc, const Ray<float>
 #ifdef RTX_WALK_STATS
     ++walk_steps;
 #endif
-    if (w.node >= 0) walk8_inner(sc, r, t_min, c.t, w, st);
+    if (w.node >= 0) walk8_inner<!ANY>(sc, r, t_min, c.t, w, st);
     else { walk8_leaf<ANY>(sc, r, t_min, c, w, st); if (ANY && c.type >= 0) return true; }
   }
 #ifdef RTX_WALK_STATS

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays 
       if (state == 1) state = occluded(sc, sr, 0.001f, t_max, st) ? 2 : 3;
     } else {
       const bool inner = state == 1 && walk8_at_inner(w);
-      if (inner) walk8_inner(sc, sr, 0.001f, c.t, w, st);
+      if (inner) walk8_inner<false>(sc, sr, 0.001f, c.t, w, st);   // any hit ends the query: no nearest-first order
       const bool leaf = state == 1 && walk8_at_leaf(w);
       if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
         if (leaf) walk8_leaf<true>(sc, sr, 0.001f, c, w, st);
