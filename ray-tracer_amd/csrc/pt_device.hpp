@@ -396,7 +396,7 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
 //   walk8_leaf   fetches ONE leaf record (a 128-byte line) and tests its up to three triangles (spheres and boxes through
 //                their tables).
 // w.node is a node record's unit (>= 0), a leaf code ~unit (< 0) or kWalkDone.  A stack entry is the group of siblings still to
-// visit under one node, three words: the node's inner_base, the unit its leaf records would start at if slot 0 were a leaf, and  slots (3 bits each, next first) | remaining
+// visit under one node, two words: the node's inner_base (where its children's records start), and  slots (3 bits each, next first) | remaining
 // count << 24 | n_inner << 28;  a child's code follows from its slot.  One entry per level at most, so levels + 1 entries always
 // suffice.  A parked child is not re-tested against the interval the hits found meanwhile have shortened (its children /
 // primitives are).  A box is entered on a <= b: the tree's own grouping may make a box flat along an axis, which must not hide
@@ -420,13 +420,13 @@ RTX_DEV uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
 // Next parked child, or kWalkDone.
 RTX_DEV int walk8_pop(Walk8& w, LaneStack st) {
   if (w.sp == 0) return kWalkDone;
-  const int e = 3 * (w.sp - 1);
-  const int ib = st.get(e), lb = st.get(e + 1);
-  const uint32_t pk = (uint32_t)st.get(e + 2);
+  const int e = 2 * (w.sp - 1);
+  const int ib = st.get(e);
+  const uint32_t pk = (uint32_t)st.get(e + 1);
   const int slot = (int)(pk & 7u), cnt = (int)((pk >> 24) & 7u), ni = (int)(pk >> 28);
   if (cnt <= 1) --w.sp;
-  else st.put(e + 2, (int)(((pk & 0x00ffffffu) >> 3) | ((uint32_t)(cnt - 1) << 24) | (pk & 0xf0000000u)));
-  return slot < ni ? ib + slot : ~(lb + 2 * slot);
+  else st.put(e + 1, (int)(((pk & 0x00ffffffu) >> 3) | ((uint32_t)(cnt - 1) << 24) | (pk & 0xf0000000u)));
+  return slot < ni ? ib + slot : ~(ib + ((ni + 1) & ~1) + 2 * (slot - ni));   // the leaf records follow the inner children from the next even unit
 }
 
 // SORTED = false (any-hit queries): the children entered are visited in slot order, the sorting network is left out.
@@ -474,8 +474,8 @@ template <bool SORTED = true> RTX_DEV void walk8_inner(const DScene<float>& sc, 
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const bool ok = key[k] != 0xffffffffu; slots |= ok ? ((uint32_t)k << at) : 0u; at += ok ? 3 : 0; }
     if (m >= 2) {
-      const int e = 3 * w.sp;
-      st.put(e, inner_base); st.put(e + 1, leaf_base); st.put(e + 2, (int)((slots >> 3) | ((uint32_t)(m - 1) << 24) | ((uint32_t)n_inner << 28)));
+      const int e = 2 * w.sp;
+      st.put(e, inner_base); st.put(e + 1, (int)((slots >> 3) | ((uint32_t)(m - 1) << 24) | ((uint32_t)n_inner << 28)));
       ++w.sp;
     }
     if (m >= 1) { const int k = (int)(slots & 7u); w.node = k < n_inner ? inner_base + k : ~(leaf_base + 2 * k); }
@@ -495,8 +495,8 @@ template <bool SORTED = true> RTX_DEV void walk8_inner(const DScene<float>& sc, 
   if (m >= 2) {   // park the siblings of the nearest child as one entry (slots beyond the count are never read)
     const uint32_t slots = (key[1] & 7u) | ((key[2] & 7u) << 3) | ((key[3] & 7u) << 6) | ((key[4] & 7u) << 9) | ((key[5] & 7u) << 12) | ((key[6] & 7u) << 15) |
                            ((key[7] & 7u) << 18);
-    const int e = 3 * w.sp;
-    st.put(e, inner_base); st.put(e + 1, leaf_base); st.put(e + 2, (int)(slots | ((uint32_t)(m - 1) << 24) | ((uint32_t)n_inner << 28)));
+    const int e = 2 * w.sp;
+    st.put(e, inner_base); st.put(e + 1, (int)(slots | ((uint32_t)(m - 1) << 24) | ((uint32_t)n_inner << 28)));
     ++w.sp;
   }
   if (m >= 1) { const int k = (int)(key[0] & 7u); w.node = k < n_inner ? inner_base + k : ~(leaf_base + 2 * k); }
@@ -518,8 +518,9 @@ RTX_DEV bool leaf_tri_t(const float* v, const Ray<float>& r, float t_min, float 
   return fabsf(a) >= 1e-8f && u >= 0.f && u <= 1.f && vv >= 0.f && u + vv <= 1.f && t >= t_min && t <= t_max;
 }
 
-template <bool ANY> RTX_DEV void walk8_leaf(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, Walk8& w, LaneStack st) {
-  const DLeaf3* lf = reinterpret_cast<const DLeaf3*>(sc.nodes8 + (~w.node));
+// Tests the primitives of the leaf record with code `leaf` (a ~unit) against the ray; updates the candidate and the tie state.
+RTX_DEV void walk8_leaf_test(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, Walk8& w, int leaf) {
+  const DLeaf3* lf = reinterpret_cast<const DLeaf3*>(sc.nodes8 + (~leaf));
   const uint4* rec = reinterpret_cast<const uint4*>(lf);
   uint4 q[8];
 #pragma unroll
@@ -546,6 +547,10 @@ template <bool ANY> RTX_DEV void walk8_leaf(const DScene<float>& sc, const Ray<f
     const bool changed = trial.type == type && trial.idx == idx && (trial.t != c.t || c.type != type || c.idx != idx);
     if (changed && !(trial.t == c.t && w.best_p >= 0 && sc.rank[p] < sc.rank[w.best_p])) { c = trial; w.best_p = p; }
   }
+}
+
+template <bool ANY> RTX_DEV void walk8_leaf(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, Walk8& w, LaneStack st) {
+  walk8_leaf_test(sc, r, t_min, c, w, w.node);
   if (ANY && c.type >= 0) { w.node = kWalkDone; return; }
   w.node = walk8_pop(w, st);
 }

@@ -69,7 +69,7 @@ struct alignas(128) DLeaf3 {
 constexpr int kLeafMaxPrims = 3;
 constexpr int kWalkDone = 0x7fffffff;
 // Words of stack a walk of a tree of `levels` node levels can need: one three-word entry per level, and one to spare.
-constexpr int walk_stack_slots(int levels) { return 3 * (levels + 1); }
+constexpr int walk_stack_slots(int levels) { return 2 * (levels + 1); }
 // Deepest eight-wide tree the kernels walk: its stack (120 words per lane) still fits the LDS of one 256-lane workgroup.  A soup of
 // 10 M triangles builds 8 levels; cuts at Morton code bits consume at least one bit of the 63 per level before ranges of equal
 // codes are halved, so only adversarial inputs get anywhere near.

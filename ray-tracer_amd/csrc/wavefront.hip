@@ -56,6 +56,10 @@ struct WfControl { uint32_t n_q[2]; uint32_t n_shadow; uint32_t cursor; };   // 
 #define RTX_LEAF_BATCH 8
 #endif
 constexpr int kLeafBatch = RTX_LEAF_BATCH;
+#ifndef RTX_WALK_MIN_WAVES
+#define RTX_WALK_MIN_WAVES 1   // waves per SIMD the traversal kernels are compiled for (caps their registers): at 72 VGPRs they run 7; 8 (64 VGPRs, spills) measured 17 % slower
+#endif
+
 
 #ifndef RTX_POOL_MULT
 #define RTX_POOL_MULT 128   // path slots per resident lane (164 B each: 11 GB at most on 256 CUs); 10 M triangles at 1080p x 64 spp: 16: 839 ms, 32: 762, 64 and up (every work item in flight): 721
@@ -266,7 +270,7 @@ RTX_DEV uint32_t feed_take(WaveFeed& f, uint32_t* cursor, bool want, uint32_t n)
 #endif
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int q, int stack_levels, DCounters* counters,
+__global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int q, int stack_levels, DCounters* counters,
                                                     const uint32_t* __restrict__ order /* the queue's entries in the order to take them */) {
   const uint32_t n = ctl->n_q[q];
   uint32_t n_nodes = 0, n_prims = 0;   // node records and leaf records this lane fetched
@@ -335,10 +339,10 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DScene<float> sc, WfArrays A
       if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
 #ifdef RTX_WALK_STATS
         { const unsigned long long ml = __ballot(leaf); if ((threadIdx.x & 63) == 0 && ml) { atomicAdd(&g_walk_stats[3], 1ull); atomicAdd(&g_walk_stats[4], (unsigned long long)__popcll(ml)); } }
-#endif
         if (leaf) { walk8_leaf<false>(sc, ray, 0.001f, c, w, st); ++n_prims; }
       }
       if (state == 1 && w.node == kWalkDone) state = 2;
+#endif
     }
   }
 #pragma unroll
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DRend
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int stack_levels,
+__global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int stack_levels,
                                                      const uint32_t* __restrict__ order /* shadow-queue indices in the order to take them, or NULL = as queued */) {
   const uint32_t n = ctl->n_shadow;
   WaveFeed feed = {0u, 0u, false};
