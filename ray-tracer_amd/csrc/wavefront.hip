@@ -339,10 +339,10 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
       if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
 #ifdef RTX_WALK_STATS
         { const unsigned long long ml = __ballot(leaf); if ((threadIdx.x & 63) == 0 && ml) { atomicAdd(&g_walk_stats[3], 1ull); atomicAdd(&g_walk_stats[4], (unsigned long long)__popcll(ml)); } }
+#endif
         if (leaf) { walk8_leaf<false>(sc, ray, 0.001f, c, w, st); ++n_prims; }
       }
       if (state == 1 && w.node == kWalkDone) state = 2;
-#endif
     }
   }
 #pragma unroll
