@@ -19,6 +19,16 @@ namespace rtx {
 template <class R> struct MVertex { V3<R> p, n; R eta; int mat; };   // ManifoldVertex, mnee.hpp:32-39 (members the solver reads)
 constexpr int kMneeMaxIter = 20, kMneeMaxDepth = 4;                  // mnee.hpp:59-60
 
+// The chain of a connection: up to kMneeMaxDepth vertices, addressed with a run-time index through selects so that the
+// vertices stay in registers (an array indexed at run time would live in scratch memory, which is where this solver spent
+// its time).
+template <class R> struct MChain {
+  MVertex<R> v0, v1, v2, v3;
+  RTX_DEV MVertex<R> get(int i) const { return i == 0 ? v0 : i == 1 ? v1 : i == 2 ? v2 : v3; }
+  RTX_DEV V3<R> p(int i) const { return i == 0 ? v0.p : i == 1 ? v1.p : i == 2 ? v2.p : v3.p; }
+  RTX_DEV void set(int i, const MVertex<R>& v) { if (i == 0) v0 = v; else if (i == 1) v1 = v; else if (i == 2) v2 = v; else v3 = v; }
+};
+
 template <class A, class B> struct mnee_same { static constexpr bool value = false; };
 template <class A> struct mnee_same<A, A> { static constexpr bool value = true; };
 template <class T, class U> RTX_DEV V3<T> v3_to(V3<U> v) { return {T(v.x), T(v.y), T(v.z)}; }
@@ -92,13 +102,14 @@ template <class S, class R, class Trace> RTX_DEV bool mnee_reproject(const DScen
 }
 
 // ref: build_path, mnee.hpp:538-617 — throughput of the chain, then a visibility walk along it
-template <class R, class SR, class Trace> RTX_DEV bool mnee_build_path(const DScene<SR>& sc, V3<R> sp, V3<R> lp, const MVertex<R>* ch, int n, R& throughput, Trace& trace) {
+template <class R, class SR, class Trace> RTX_DEV bool mnee_build_path(const DScene<SR>& sc, V3<R> sp, V3<R> lp, const MChain<R>& ch, int n, R& throughput, Trace& trace) {
   throughput = R(1);
   for (int i = 0; i < n; ++i) {
-    V3<R> prev = (i == 0) ? sp : ch[i - 1].p, next = (i == n - 1) ? lp : ch[i + 1].p, cur = ch[i].p;
+    const MVertex<R> vi = ch.get(i);
+    V3<R> prev = (i == 0) ? sp : ch.p(i - 1), next = (i == n - 1) ? lp : ch.p(i + 1), cur = vi.p;
     V3<R> wi = normalize(prev - cur), wo = normalize(next - cur);
-    R eta = ch[i].eta;
-    R cos_i = abs_(dot(wi, ch[i].n)), cos_t = abs_(dot(wo, ch[i].n));
+    R eta = vi.eta;
+    R cos_i = abs_(dot(wi, vi.n)), cos_t = abs_(dot(wo, vi.n));
     R r0 = (R(1) - eta) / (R(1) + eta);
     r0 = r0 * r0;
     R fr;
@@ -114,53 +125,63 @@ template <class R, class SR, class Trace> RTX_DEV bool mnee_build_path(const DSc
   }
   V3<R> current = sp;
   for (int i = 0; i <= n; ++i) {
-    V3<R> target = (i == n) ? lp : ch[i].p;
+    V3<R> target = (i == n) ? lp : ch.p(i);
     V3<R> dir = normalize(target - current);
     R dist = len(target - current);
     Hit<SR> rec;
     V3<R> hp, hn;
     if (mnee_trace(sc, current, dir, R(0.001), dist - R(0.001), rec, hp, hn, trace)) {
       if (i < n) {
-        R hd = len(hp - ch[i].p);
+        R hd = len(hp - ch.p(i));
         if (hd > R(0.01)) return false;
       } else return false;
     }
-    if (i < n) current = ch[i].p;
+    if (i < n) current = ch.p(i);
   }
   return true;
 }
 
 // ref: solve_manifold, mnee.hpp:442-533 — Gauss-Seidel Newton on the per-vertex refraction
 // constraints with finite-difference 2x2 Jacobians (compute_jacobian_block :354-382, solve_2x2 :387-396)
-template <class R, class SR, class Trace> RTX_DEV bool mnee_solve(const DScene<SR>& sc, V3<R> sp, V3<R> lp, MVertex<R>* ch, int n, R& throughput, Trace& trace) {
-  V3<R> tg[kMneeMaxDepth], bt[kMneeMaxDepth];
-  for (int i = 0; i < n; ++i) mnee_frame(ch[i].n, tg[i], bt[i]);
+template <class R, class SR, class Trace> RTX_DEV bool mnee_solve(const DScene<SR>& sc, V3<R> sp, V3<R> lp, MChain<R>& ch, int n, R& throughput, Trace& trace) {
+  // (the reference keeps every vertex's tangent frame in an array and renews it after the vertex's re-projection; a frame is a
+  // function of the vertex's normal alone, so it is computed where it is used: the same values, a dozen registers fewer per vertex)
   for (int iter = 0; iter < kMneeMaxIter; ++iter) {
-    R max_c = R(0), cu[kMneeMaxDepth], cv[kMneeMaxDepth];
+    R max_c = R(0);
+    R c_u0 = R(0), c_u1 = R(0), c_u2 = R(0), c_u3 = R(0), c_v0 = R(0), c_v1 = R(0), c_v2 = R(0), c_v3 = R(0);   // cu[i], cv[i]
     for (int i = 0; i < n; ++i) {
-      V3<R> prev = (i == 0) ? sp : ch[i - 1].p, next = (i == n - 1) ? lp : ch[i + 1].p;
-      mnee_constraint(prev, ch[i].p, next, ch[i].eta, tg[i], bt[i], cu[i], cv[i]);
-      R mag = sqrt_(cu[i] * cu[i] + cv[i] * cv[i]);
+      const MVertex<R> vi = ch.get(i);
+      V3<R> prev = (i == 0) ? sp : ch.p(i - 1), next = (i == n - 1) ? lp : ch.p(i + 1);
+      V3<R> tg, bt;
+      mnee_frame(vi.n, tg, bt);
+      R cu, cv;
+      mnee_constraint(prev, vi.p, next, vi.eta, tg, bt, cu, cv);
+      if (i == 0) { c_u0 = cu; c_v0 = cv; } else if (i == 1) { c_u1 = cu; c_v1 = cv; } else if (i == 2) { c_u2 = cu; c_v2 = cv; } else { c_u3 = cu; c_v3 = cv; }
+      R mag = sqrt_(cu * cu + cv * cv);
       max_c = max_(max_c, mag);
     }
     if (max_c < R(1e-6)) return mnee_build_path(sc, sp, lp, ch, n, throughput, trace);
     for (int i = 0; i < n; ++i) {
-      V3<R> prev = (i == 0) ? sp : ch[i - 1].p, next = (i == n - 1) ? lp : ch[i + 1].p;
+      MVertex<R> vi = ch.get(i);
+      V3<R> prev = (i == 0) ? sp : ch.p(i - 1), next = (i == n - 1) ? lp : ch.p(i + 1);
+      V3<R> tg, bt;
+      mnee_frame(vi.n, tg, bt);
+      const R cu_i = i == 0 ? c_u0 : i == 1 ? c_u1 : i == 2 ? c_u2 : c_u3, cv_i = i == 0 ? c_v0 : i == 1 ? c_v1 : i == 2 ? c_v2 : c_v3;
       const R h = R(1e-5);
       R c0u, c0v, cuu, cuv, cvu, cvv;
-      mnee_constraint(prev, ch[i].p, next, ch[i].eta, tg[i], bt[i], c0u, c0v);
-      mnee_constraint(prev, ch[i].p + tg[i] * h, next, ch[i].eta, tg[i], bt[i], cuu, cuv);
-      mnee_constraint(prev, ch[i].p + bt[i] * h, next, ch[i].eta, tg[i], bt[i], cvu, cvv);
+      mnee_constraint(prev, vi.p, next, vi.eta, tg, bt, c0u, c0v);
+      mnee_constraint(prev, vi.p + tg * h, next, vi.eta, tg, bt, cuu, cuv);
+      mnee_constraint(prev, vi.p + bt * h, next, vi.eta, tg, bt, cvu, cvv);
       R J00 = (cuu - c0u) / h, J01 = (cvu - c0u) / h, J10 = (cuv - c0v) / h, J11 = (cvv - c0v) / h;
-      R b0 = -cu[i], b1 = -cv[i], st0, st1;
+      R b0 = -cu_i, b1 = -cv_i, st0, st1;
       R det = J00 * J11 - J01 * J10;
-      if (abs_(det) < R(1e-10)) { st0 = R(-0.5) * cu[i]; st1 = R(-0.5) * cv[i]; }
+      if (abs_(det) < R(1e-10)) { st0 = R(-0.5) * cu_i; st1 = R(-0.5) * cv_i; }
       else { R inv = R(1) / det; st0 = inv * (J11 * b0 - J01 * b1); st1 = inv * (-J10 * b0 + J00 * b1); }
       R mag = sqrt_(st0 * st0 + st1 * st1);
-      if (mag > R(0.1)) { R sc = R(0.1) / mag; st0 *= sc; st1 *= sc; }
-      ch[i].p = ch[i].p + (tg[i] * st0 + bt[i] * st1);
-      mnee_reproject(sc, ch[i].p, ch[i].n, ch[i].mat, trace);
-      mnee_frame(ch[i].n, tg[i], bt[i]);
+      if (mag > R(0.1)) { R sc2 = R(0.1) / mag; st0 *= sc2; st1 *= sc2; }
+      vi.p = vi.p + (tg * st0 + bt * st1);
+      mnee_reproject(sc, vi.p, vi.n, vi.mat, trace);
+      ch.set(i, vi);
     }
   }
   return false;
@@ -168,7 +189,7 @@ template <class R, class SR, class Trace> RTX_DEV bool mnee_solve(const DScene<S
 
 // ref: connect_to_light_straight, mnee.hpp:94-143 — the chain of dielectric crossings on the straight line to the light.
 // Returns its length; 0 = no chain (nothing in the way, or something that is not a dielectric).
-template <class R, class SR, class Trace> RTX_DEV int mnee_straight_chain(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<R> sp, V3<R> lp, MVertex<R>* ch, Trace& trace) {
+template <class R, class SR, class Trace> RTX_DEV int mnee_straight_chain(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<R> sp, V3<R> lp, MChain<R>& ch, Trace& trace) {
   V3<R> to_light = lp - sp;
   R dist = len(to_light);
   V3<R> dir = to_light * (R(1) / dist);
@@ -183,9 +204,11 @@ template <class R, class SR, class Trace> RTX_DEV int mnee_straight_chain(const 
     // a quad / disk light in the way has a negative id (the reference indexes its material
     // array with it: undefined behaviour); defined here as "not a dielectric"
     if (rec.mat < 0 || mats[rec.mat].type != MAT_DIELECTRIC) return 0;
-    ch[n].p = hp; ch[n].n = hn;
-    ch[n].eta = rec.front ? (R(1) / R(mats[rec.mat].ior)) : R(mats[rec.mat].ior);
-    ch[n].mat = rec.mat;
+    MVertex<R> v;
+    v.p = hp; v.n = hn;
+    v.eta = rec.front ? (R(1) / R(mats[rec.mat].ior)) : R(mats[rec.mat].ior);
+    v.mat = rec.mat;
+    ch.set(n, v);
     ++n;
     cur = hp;
     probe_o = cur + dir * R(0.001);
@@ -206,7 +229,7 @@ template <class R, class SR> RTX_DEV bool mnee_sphere_hit(const DSphere<SR>& s0,
 }
 
 // ref: try_sphere_seed_path, mnee.hpp:194-295 — the two-vertex seed chain through one dielectric sphere.  Returns 2, or 0.
-template <class R, class SR> RTX_DEV int mnee_sphere_seed_chain(const DSphere<SR>& sph0, const DMaterial<SR>& m0, V3<R> sp, V3<R> lp, MVertex<R>* ch) {
+template <class R, class SR> RTX_DEV int mnee_sphere_seed_chain(const DSphere<SR>& sph0, const DMaterial<SR>& m0, V3<R> sp, V3<R> lp, MChain<R>& ch) {
   struct { R radius; int mat; } sph = {R(sph0.radius), sph0.mat};
   struct { R ior; } m = {R(m0.ior)};
   V3<R> c = {R(sph0.c[0]), R(sph0.c[1]), R(sph0.c[2])};
@@ -226,8 +249,8 @@ template <class R, class SR> RTX_DEV int mnee_sphere_seed_chain(const DSphere<SR
       nrm[k] = normalize(pts[k] - c);
     }
   }
-  ch[0].p = pts[0]; ch[0].n = nrm[0]; ch[0].eta = R(1) / m.ior; ch[0].mat = sph.mat;
-  ch[1].p = pts[1]; ch[1].n = -nrm[1]; ch[1].eta = m.ior; ch[1].mat = sph.mat;
+  ch.v0.p = pts[0]; ch.v0.n = nrm[0]; ch.v0.eta = R(1) / m.ior; ch.v0.mat = sph.mat;
+  ch.v1.p = pts[1]; ch.v1.n = -nrm[1]; ch.v1.eta = m.ior; ch.v1.mat = sph.mat;
   return 2;
 }
 
@@ -236,7 +259,7 @@ template <class R, class SR> RTX_DEV int mnee_sphere_seed_chain(const DSphere<SR
 // loop over the attempts, so that the solver and its closest-hit queries are instantiated once.)
 template <class R, class SR, class Trace> RTX_DEV bool mnee_connect(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<R> sp, V3<R> lp, R& throughput, Trace& trace) {
   for (int i = -1; i < sc.n_spheres; ++i) {
-    MVertex<R> ch[kMneeMaxDepth];
+    MChain<R> ch{};
     int n = 0;
     if (i < 0) {
       n = mnee_straight_chain(sc, mats, sp, lp, ch, trace);
