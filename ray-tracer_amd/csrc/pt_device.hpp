@@ -1137,10 +1137,11 @@ enum : uint32_t { STEP_SHADOW = 1u, STEP_SHADED = 2u };
 // the kernel staged one).
 // MNEE = true adds manifold next event estimation at Lambertian vertices (ref: engine/renderer.cpp:716-732);
 // it needs `shadow` to return whether the light sample was visible (the reference skips MNEE when an
-// unoccluded sample is rejected, :691/:695) and `trace`, a closest-hit functor (see pt_mnee.hpp).
-template <class R, bool MNEE, bool NMAP, class ShadowFn, class TraceFn>
+// unoccluded sample is rejected, :691/:695) and `mnee(point, albedo, bounce)`, which evaluates it (pt_mnee.hpp) and adds to
+// ps.acc.  It is called with ps.thr still the throughput ahead of this vertex.
+template <class R, bool MNEE, bool NMAP, class ShadowFn, class MneeFn>
 RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
-                                  const DRenderParams& P, PathKey key, ShadowFn&& shadow, TraceFn&& trace) {
+                                  const DRenderParams& P, PathKey key, ShadowFn&& shadow, MneeFn&& mnee) {
   const bool nee = P.use_nee != 0, mis = P.use_mis != 0;
   const bool env_is = sc.env.importance != 0;
   uint32_t did = 0;
@@ -1242,13 +1243,7 @@ RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, Hit<R>& rec,
         }
       }
       if constexpr (MNEE) {
-        if (!skip_mnee) {
-          V3<R> mc;
-          if (mnee_evaluate(sc, mats, rec.p, key, bounce, mc, trace)) {
-            V3<R> md = ((mc * surf) * ps.thr) * (R(1) / R(3.14159265358979323846));
-            ps.acc = ps.acc + md;
-          }
-        }
+        if (!skip_mnee) mnee(rec.p, surf, bounce);
       }
     }
     sdir = rec.n + unit_vector(u16hi<R>(rn.y), u16lo<R>(rn.y));   // ref: engine/renderer.cpp:737-743
@@ -1308,7 +1303,7 @@ RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, Hit<R>& rec,
 template <class R, bool NMAP, class ShadowFn>
 RTX_DEV uint32_t path_vertex(PathState<R>& ps, const bool hit, Hit<R>& rec, const DScene<R>& sc, const DMaterial<R>* mats,
                              const DRenderParams& P, PathKey key, ShadowFn&& shadow) {
-  return path_vertex_impl<R, false, NMAP>(ps, hit, rec, sc, mats, P, key, shadow, [](const Ray<R>&, R, R, Hit<R>&) { return false; });
+  return path_vertex_impl<R, false, NMAP>(ps, hit, rec, sc, mats, P, key, shadow, [](V3<R>, V3<R>, int) {});
 }
 
 // Renderer::ray_color_whitted (ref: engine/renderer.cpp:483-569) unrolled into one vertex per call:
@@ -1391,9 +1386,16 @@ RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMateria
           if (visible) ps.acc = ps.acc + contrib;
           return visible;
         },
-        [&](const Ray<R>& r, R t_min, R t_max, Hit<R>& h) {
-          ++extra_traces;
-          return trace_closest<R, MODE>(sc, r, t_min, t_max, h, st);
+        [&](V3<R> hp, V3<R> surf, int bounce) {   // MNEE::evaluate on the spot (ref: engine/renderer.cpp:716-732)
+          auto trace = [&](const Ray<R>& r, R t_min, R t_max, Hit<R>& h) {
+            ++extra_traces;
+            return trace_closest<R, MODE>(sc, r, t_min, t_max, h, st);
+          };
+          V3<R> mc;
+          if (mnee_evaluate(sc, mats, hp, key, bounce, mc, trace)) {
+            V3<R> md = ((mc * surf) * ps.thr) * (R(1) / R(3.14159265358979323846));
+            ps.acc = ps.acc + md;
+          }
         });
   }
 }

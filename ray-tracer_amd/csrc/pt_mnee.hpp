@@ -288,80 +288,103 @@ template <class R> RTX_DEV void mnee_pair(PathKey key, int bounce, int j, R& a, 
   a = u16hi<R>(w); b = u16lo<R>(w);
 }
 
-// ref: MNEE::evaluate, mnee.hpp:632-763.  Returns whether any light contributed.
-template <class SR, class Trace> RTX_DEV bool mnee_evaluate(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<SR> hp0, PathKey key, int bounce, V3<SR>& contribution_out, Trace& trace) {
+// One light's sample point as MNEE::evaluate draws it (ref: mnee.hpp:632-763): the lights in the reference's order - quads,
+// disks, then the spheres (in index order) whose material is emissive -, light j with the j-th pair of uniforms.
+template <class R> struct MneeLight { V3<R> lp, ln, Le, sd; R area, ctm; bool sphere; };
+
+template <class SR> RTX_DEV int mnee_light_count(const DScene<SR>& sc) { return sc.n_quads + sc.n_disks + sc.n_emissive; }
+
+template <class SR> RTX_DEV MneeLight<double> mnee_light(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<double> hp, PathKey key, int bounce, int j) {
   using R = double;   // the type the walk computes in; SR is the scene's
   auto mk3 = [](const SR* a) { return V3<R>{R(a[0]), R(a[1]), R(a[2])}; };
+  const R two_pi = R(2) * R(3.14159265358979323846);
+  const int nq = sc.n_quads, nd = sc.n_disks;
+  MneeLight<R> L;
+  R u, v;
+  mnee_pair(key, bounce, j, u, v);
+  L.sd = {R(0), R(0), R(0)};
+  L.area = R(0); L.ctm = R(0);
+  L.sphere = j >= nq + nd;
+  if (j < nq) {
+    const DQuad<SR>& q = sc.quads[j];
+    L.lp = mk3(q.corner) + (mk3(q.eu) * u + mk3(q.ev) * v);   // ref: QuadLight::sample_point, primitives.hpp:258-262
+    L.ln = mk3(q.n); L.Le = mk3(q.Le); L.area = R(q.area);
+  } else if (!L.sphere) {
+    const DDisk<SR>& dl = sc.disks[j - nq];
+    L.lp = mk3(dl.c);   // ref: DiskLight::sample_point, primitives.hpp:350-384
+    R sx = R(2) * u - R(1), sy = R(2) * v - R(1);
+    if (!(sx == R(0) && sy == R(0))) {
+      R rs, theta;
+      if (abs_(sx) > abs_(sy)) { rs = sx; theta = (Consts<R>::pi / R(4)) * (sy / sx); }
+      else { rs = sy; theta = (Consts<R>::pi / R(2)) - (Consts<R>::pi / R(4)) * (sx / sy); }
+      R st, ct;
+      sincos_(theta, &st, &ct);
+      R ar = R(dl.radius) * rs;
+      L.lp = L.lp + (mk3(dl.tan) * (ar * ct) + mk3(dl.bit) * (ar * st));
+    }
+    L.ln = mk3(dl.n); L.Le = mk3(dl.Le); L.area = R(dl.area);
+  } else {
+    const DSphere<SR>& sph = sc.spheres[sc.emissive[j - nq - nd]];
+    V3<R> to_sphere = mk3(sph.c) - hp;
+    R dc = len(to_sphere);
+    V3<R> w3 = to_sphere * (R(1) / dc);
+    const R radius = R(sph.radius);
+    L.ctm = sqrt_(R(1) - (radius * radius) / (dc * dc));
+    if (L.ctm < R(0)) L.ctm = R(0);
+    const R r1 = u, r2 = v;
+    R ct = R(1) + r1 * (L.ctm - R(1));
+    R sn = sqrt_(R(1) - ct * ct);
+    R phi = two_pi * r2;
+    V3<R> uv = (abs_(w3.x) > R(0.9)) ? V3<R>{R(0), R(1), R(0)} : V3<R>{R(1), R(0), R(0)};
+    uv = normalize(cross(w3, uv));
+    V3<R> vv = cross(w3, uv);
+    R sphi, cphi;
+    sincos_(phi, &sphi, &cphi);
+    L.sd = uv * (sn * cphi) + (vv * (sn * sphi) + w3 * ct);
+    R t = dc * ct - sqrt_(radius * radius - dc * dc * (R(1) - ct * ct));
+    L.lp = hp + L.sd * t;
+    L.ln = normalize(L.lp - mk3(sph.c));
+    L.Le = mk3(mats[sph.mat].emission);
+  }
+  return L;
+}
+
+// What a converged connection of throughput w to that sample contributes.
+RTX_DEV V3<double> mnee_light_contribution(const MneeLight<double>& L, V3<double> hp, double w) {
+  using R = double;
+  const R two_pi = R(2) * R(3.14159265358979323846);
+  if (L.sphere) {
+    R solid = two_pi * (R(1) - L.ctm);
+    R pdf = R(1) / solid;
+    R cal = abs_(dot(L.ln, -L.sd));
+    return L.Le * (w * cal / pdf);
+  }
+  V3<R> to_light = L.lp - hp;
+  R d2 = len2(to_light);
+  R cl = abs_(dot(L.ln, normalize(-to_light)));
+  R lpdf = d2 / (L.area * cl);
+  return L.Le * (w * cl / (d2 * lpdf));
+}
+
+// One light of MNEE::evaluate: sample, connect, weigh.
+template <class SR, class Trace> RTX_DEV bool mnee_evaluate_light(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<double> hp, PathKey key, int bounce, int j, V3<double>& c, Trace& trace) {
+  const MneeLight<double> L = mnee_light(sc, mats, hp, key, bounce, j);
+  double w;
+  if (!mnee_connect(sc, mats, hp, L.lp, w, trace)) return false;
+  c = mnee_light_contribution(L, hp, w);
+  return true;
+}
+
+// ref: MNEE::evaluate, mnee.hpp:632-763.  Returns whether any light contributed.
+template <class SR, class Trace> RTX_DEV bool mnee_evaluate(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<SR> hp0, PathKey key, int bounce, V3<SR>& contribution_out, Trace& trace) {
+  using R = double;
   const V3<R> hp = v3_to<R>(hp0);
   V3<R> contribution = {R(0), R(0), R(0)};
   bool any = false;
-  const R two_pi = R(2) * R(3.14159265358979323846);
-  // the lights in the reference's order: quads, disks, then the spheres (in index order) whose material is emissive; light j
-  // draws the j-th pair of uniforms.  One loop, so that mnee_connect is instantiated once.
-  const int nq = sc.n_quads, nd = sc.n_disks, total = nq + nd + sc.n_emissive;
-  for (int j = 0; j < total; ++j) {
-    R u, v;
-    mnee_pair(key, bounce, j, u, v);
-    V3<R> lp, ln, Le, sd = {R(0), R(0), R(0)};
-    R area = R(0), ctm = R(0);
-    const bool sphere = j >= nq + nd;
-    if (j < nq) {
-      const DQuad<SR>& q = sc.quads[j];
-      lp = mk3(q.corner) + (mk3(q.eu) * u + mk3(q.ev) * v);   // ref: QuadLight::sample_point, primitives.hpp:258-262
-      ln = mk3(q.n); Le = mk3(q.Le); area = R(q.area);
-    } else if (!sphere) {
-      const DDisk<SR>& dl = sc.disks[j - nq];
-      lp = mk3(dl.c);   // ref: DiskLight::sample_point, primitives.hpp:350-384
-      R sx = R(2) * u - R(1), sy = R(2) * v - R(1);
-      if (!(sx == R(0) && sy == R(0))) {
-        R rs, theta;
-        if (abs_(sx) > abs_(sy)) { rs = sx; theta = (Consts<R>::pi / R(4)) * (sy / sx); }
-        else { rs = sy; theta = (Consts<R>::pi / R(2)) - (Consts<R>::pi / R(4)) * (sx / sy); }
-        R st, ct;
-        sincos_(theta, &st, &ct);
-        R ar = R(dl.radius) * rs;
-        lp = lp + (mk3(dl.tan) * (ar * ct) + mk3(dl.bit) * (ar * st));
-      }
-      ln = mk3(dl.n); Le = mk3(dl.Le); area = R(dl.area);
-    } else {
-      const DSphere<SR>& sph = sc.spheres[sc.emissive[j - nq - nd]];
-      V3<R> to_sphere = mk3(sph.c) - hp;
-      R dc = len(to_sphere);
-      V3<R> w3 = to_sphere * (R(1) / dc);
-      const R radius = R(sph.radius);
-      ctm = sqrt_(R(1) - (radius * radius) / (dc * dc));
-      if (ctm < R(0)) ctm = R(0);
-      const R r1 = u, r2 = v;
-      R ct = R(1) + r1 * (ctm - R(1));
-      R sn = sqrt_(R(1) - ct * ct);
-      R phi = two_pi * r2;
-      V3<R> uv = (abs_(w3.x) > R(0.9)) ? V3<R>{R(0), R(1), R(0)} : V3<R>{R(1), R(0), R(0)};
-      uv = normalize(cross(w3, uv));
-      V3<R> vv = cross(w3, uv);
-      R sphi, cphi;
-      sincos_(phi, &sphi, &cphi);
-      sd = uv * (sn * cphi) + (vv * (sn * sphi) + w3 * ct);
-      R t = dc * ct - sqrt_(radius * radius - dc * dc * (R(1) - ct * ct));
-      lp = hp + sd * t;
-      ln = normalize(lp - mk3(sph.c));
-      Le = mk3(mats[sph.mat].emission);
-    }
-    R w;
-    if (mnee_connect(sc, mats, hp, lp, w, trace)) {
-      if (sphere) {
-        R solid = two_pi * (R(1) - ctm);
-        R pdf = R(1) / solid;
-        R cal = abs_(dot(ln, -sd));
-        contribution = contribution + Le * (w * cal / pdf);
-      } else {
-        V3<R> to_light = lp - hp;
-        R d2 = len2(to_light);
-        R cl = abs_(dot(ln, normalize(-to_light)));
-        R lpdf = d2 / (area * cl);
-        contribution = contribution + Le * (w * cl / (d2 * lpdf));
-      }
-      any = true;
-    }
+  const int total = mnee_light_count(sc);
+  for (int j = 0; j < total; ++j) {   // one loop, so that mnee_connect is instantiated once
+    V3<R> c;
+    if (mnee_evaluate_light(sc, mats, hp, key, bounce, j, c, trace)) { contribution = contribution + c; any = true; }
   }
   contribution_out = v3_to<SR>(contribution);
   return any;
