@@ -93,6 +93,58 @@ def test_fast_path_closest_hit_agreement(name, pkg, tracer, load_scene):
     assert int((~agree).sum()) <= F32_ID_MISMATCH_RAYS.get(name, 0), int((~agree).sum())
 
 
+@pytest.mark.parametrize("n_tris,n_spheres,n_boxes", [(13, 0, 0), (0, 13, 0), (5, 5, 4), (27, 3, 2), (64, 0, 1), (65, 7, 0), (500, 13, 11), (5000, 50, 50), (40000, 0, 0)])
+def test_mixed_primitive_trees_of_many_sizes(n_tris, n_spheres, n_boxes, pkg, tracer, load_scene):
+    """Trees of one node, of odd and even numbers of inner children, and of several levels, over triangles, spheres and boxes
+    mixed: the production walks find the primitive the reference-order walk (Scene::hit, engine/scene.hpp:574-674) finds.  In
+    double every ray must agree, bits of t included; in single precision a ray that grazes an edge may differ."""
+    import copy
+    sd = copy.copy(load_scene("cornell_box_quad"))
+    sd._keep = []
+    sd.spheres, sd.boxes, sd.triangles = [], [], []
+    seed = 1000 + n_tris + 7 * n_spheres + 13 * n_boxes
+    size = 0.5 if n_tris + n_spheres + n_boxes < 100 else 0.15
+    if n_tris:
+        soup = pkg.synthetic.triangle_soup(n_tris, seed=seed, extent=2.2, size=size, n_materials=3)
+        for k in ("v0", "v1", "v2"):
+            soup[k] += (0, 2.5, -2.5)
+        sd.triangle_array = soup
+    else:
+        sd.triangle_array = None
+    idx = np.arange(max(n_spheres, n_boxes, 1), dtype=np.uint64)
+    u = [pkg.synthetic.hash_uniform(idx, 40 + k, seed) for k in range(7)]
+    for i in range(n_spheres):
+        s = pkg.abi.Sphere()
+        s.center[:] = ((u[0][i] * 2 - 1) * 2.2, 2.5 + (u[1][i] * 2 - 1) * 2.2, -2.5 + (u[2][i] * 2 - 1) * 2.2)
+        s.radius, s.material_id = size * (0.3 + u[3][i]), i % 3
+        sd.spheres.append(s)
+    for i in range(n_boxes):
+        b = pkg.abi.Box()
+        lo = np.array(((u[4][i] * 2 - 1) * 2.2, 2.5 + (u[5][i] * 2 - 1) * 2.2, -2.5 + (u[6][i] * 2 - 1) * 2.2))
+        b.box_min[:] = tuple(lo)
+        b.box_max[:] = tuple(lo + size * (0.2 + np.array((u[0][i], u[1][i], u[2][i]))))
+        b.material_id = i % 3
+        sd.boxes.append(b)
+    pt = tracer(sd)
+    info = pt.bvh_info()
+    assert info.ref_prims == n_tris + n_spheres + n_boxes and info.wide_nodes >= 1
+    rays = pkg.synthetic.stress_rays(20000, seed=seed, half=2.7)
+    rays[:, 1] += 2.5
+    rays[:, 2] -= 2.5
+    exp = pt.trace_closest(rays)
+    assert exp["hit"].mean() > 0.5
+    f64 = pt.trace_closest(rays, pkg.abi.PRECISION_F64)
+    for f in ("hit", "prim_type", "prim_index"):
+        assert np.array_equal(f64[f], exp[f]), f
+    assert np.array_equal(bits(f64["t"]), bits(exp["t"]))
+    f32 = pt.trace_closest(rays, pkg.abi.PRECISION_F32)
+    differ = int(((f32["hit"] != exp["hit"]) | (f32["prim_type"] != exp["prim_type"]) | (f32["prim_index"] != exp["prim_index"])).sum())
+    record_rate(f"f32_id_mismatch_mixed_{n_tris}_{n_spheres}_{n_boxes}", rate=differ / len(rays), mismatching=differ, rays=len(rays))
+    assert differ <= 20, differ
+    hit = (f32["hit"] == 1) & (exp["hit"] == 1) & (f32["prim_index"] == exp["prim_index"]) & (f32["prim_type"] == exp["prim_type"])
+    assert np.abs(f32["t"][hit] - exp["t"][hit]).max() < 1e-3 * (1 + np.abs(exp["t"][hit]).max())
+
+
 def test_edge_cases_empty_and_degenerate(pkg, tracer, load_scene):
     pt = tracer(load_scene("cornell_box"))
     assert pt.trace_closest(np.zeros((0, 8))).shape == (0,)
