@@ -140,7 +140,7 @@ def test_mixed_primitive_trees_of_many_sizes(n_tris, n_spheres, n_boxes, pkg, tr
     f32 = pt.trace_closest(rays, pkg.abi.PRECISION_F32)
     differ = int(((f32["hit"] != exp["hit"]) | (f32["prim_type"] != exp["prim_type"]) | (f32["prim_index"] != exp["prim_index"])).sum())
     record_rate(f"f32_id_mismatch_mixed_{n_tris}_{n_spheres}_{n_boxes}", rate=differ / len(rays), mismatching=differ, rays=len(rays))
-    assert differ <= 20, differ
+    assert differ <= 2, differ   # measured: 0 of 20 000 in every case
     hit = (f32["hit"] == 1) & (exp["hit"] == 1) & (f32["prim_index"] == exp["prim_index"]) & (f32["prim_type"] == exp["prim_type"])
     assert np.abs(f32["t"][hit] - exp["t"][hit]).max() < 1e-3 * (1 + np.abs(exp["t"][hit]).max())
 
