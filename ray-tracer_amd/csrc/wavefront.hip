@@ -1,18 +1,19 @@
 // Wavefront (queue-based) pipeline, single precision.
 //
-// A pool of path slots lives in HBM as structure-of-arrays.  One iteration advances every live
-// path by one vertex with three kernels:
+// A pool of path slots lives in HBM as structure-of-arrays.  wf_start gives every slot its first
+// (pixel, chunk) work item and camera ray; after that one turn advances every live path by one
+// vertex with three kernels:
 //
-//   wf_generate         slots whose path ended add it to their chunk sum and start the next
-//                       sample (or fetch the next (pixel, chunk) work item); slots that still have
-//                       a ray to trace are compacted into the next ray queue
 //   wf_extend           every queued slot's ray is traced to its closest hit
 //   wf_shade            the vertex is shaded (emission, MIS, light sample, scatter, roulette);
 //                       light samples that need a visibility test are compacted into the
-//                       shadow-ray queue
+//                       shadow-ray queue; a slot whose path ended adds it to its chunk sum and
+//                       starts its next sample (or takes its next work item) on the spot; slots
+//                       with a ray to trace are compacted into the next ray queue
 //   wf_connect          shadow rays are traced (any hit); unoccluded ones add their contribution
+//                       to the chunk sum of their slot
 //
-// Queues are compacted with wave-level ballot + prefix popcount and ONE atomic per wave.
+// Queues are compacted with ballot + prefix popcount and ONE atomic per workgroup.
 // The traversal kernels carry only a ray and a candidate, so they run at 2-4x the occupancy
 // of the fused kernel; that is what pays for the queue traffic on scenes that walk a tree.
 // Per-slot arithmetic and sample order equal the fused kernel's, so films agree to rounding.
@@ -47,7 +48,13 @@ struct WfArrays {
   uint32_t n_slots;
 };
 
-struct WfControl { uint32_t n_q[2]; uint32_t n_shadow; uint32_t cursor; };   // cursor: next queue entry a persistent kernel hands out
+// Queue lengths and the cursors the persistent kernels hand their entries out from.  No kernel runs between wf_connect and the
+// wf_extend after it, so each has a cursor of its own; the counters rotate so that the one a turn fills was cleared a turn earlier
+// (by wf_shade, after every kernel that read it has finished).
+struct WfControl { uint32_t n_q[3]; uint32_t n_shadow[2]; uint32_t cursor_rays, cursor_shadow; };
+// One turn: wf_shade reads the ray queue A.q[q_in] of n_q[n_in] entries, fills A.q[q_out] / n_q[n_out] and clears n_q[n_zero];
+// its shadow rays are counted in n_shadow[sh] (it clears the other one).
+struct WfTurn { int q_in, q_out, n_in, n_out, n_zero, sh; };
 
 // A persistent traversal wave runs the leaf phase when at least this many lanes have a leaf pending (or none has a node).
 // A leaf phase costs about as many instructions as a node phase and, one leaf per four nodes, serves a fifth of the lanes:
@@ -125,68 +132,43 @@ RTX_DEV void block_count2(BlockScratch& bs, unsigned long long* counter_a, bool 
   }
 }
 
-// Slots whose path ended add it to their chunk sum and start the next sample (or take the next
-// (pixel, chunk) work item); every slot that still has a ray to trace goes into the next queue.
-__global__ __launch_bounds__(kStreamBlock) void wf_generate(DCamera<float> cam, DRenderParams P, WfArrays A, WfControl* ctl, int first, int qin, int qout,
-                                                      float* __restrict__ partial, DCounters* counters) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t n = first ? A.n_slots : ctl->n_q[qin];
+// (pixel, chunk) work item `item` of a render: where its pixel lies and which samples it covers.
+struct WorkItem { uint32_t xy, pixel, s_begin, s_end; };
+RTX_DEV WorkItem work_item(const DRenderParams& P, uint32_t item) {
+  const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
+  const uint32_t chunk = item / npix;
+  const uint32_t pix = item - chunk * npix;
+  const uint32_t row_local = pix / (uint32_t)P.width;
+  const uint32_t x = pix - row_local * (uint32_t)P.width;
+  const uint32_t y = (uint32_t)P.shard_index + row_local * (uint32_t)P.shard_count;
+  const uint32_t s = chunk * (uint32_t)P.chunk_spp;
+  return {(y << 16) | x, y * (uint32_t)P.width + x, s, s + (uint32_t)P.chunk_spp < (uint32_t)P.spp ? s + (uint32_t)P.chunk_spp : (uint32_t)P.spp};
+}
+
+// Slot i takes work item i (a render has at least as many items as slots) and starts its first sample; all slots go into ray
+// queue 0.
+__global__ __launch_bounds__(kStreamBlock) void wf_start(DCamera<float> cam, DRenderParams P, WfArrays A, WfControl* ctl, DCounters* counters) {
+  const uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ BlockScratch bs;
-  if (i == 0) { ctl->cursor = 0u; ctl->n_shadow = 0u; }   // wf_connect is done with both; wf_extend and the next wf_shade start from zero
-  const bool valid = i < n;
-  const uint32_t sl = !valid ? 0u : first ? i : A.q[qin][i];
-  const uint32_t bf = (first || !valid) ? 0u : A.bflags[sl];
-  bool live = valid, started = false;
-  if (valid && !(bf & F_ALIVE)) {
-    const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
-    const uint32_t n_items = npix * (uint32_t)P.n_chunks;
-    uint32_t s = first ? 0u : A.sample[sl], s_end = first ? 0u : A.s_end[sl];
-    V3<float> sum = {0.f, 0.f, 0.f};
-    if (!first) sum = {A.sum[0][sl] + A.acc[0][sl], A.sum[1][sl] + A.acc[1][sl], A.sum[2][sl] + A.acc[2][sl]};
-    uint32_t pixel = 0, xy = 0;
-    if (s == s_end) {
-      if (s_end != 0u) {
-        float* o = partial + (size_t)A.cur[sl] * 3u;
-        o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
-      }
-      const uint32_t item = first ? sl : A.next[sl];
-      if (item >= n_items) {
-        live = false;
-        A.s_end[sl] = 0u; A.sample[sl] = 0u;
-      } else {
-        const uint32_t chunk = item / npix;
-        const uint32_t pix = item - chunk * npix;
-        const uint32_t row_local = pix / (uint32_t)P.width;
-        const uint32_t x = pix - row_local * (uint32_t)P.width;
-        const uint32_t y = (uint32_t)P.shard_index + row_local * (uint32_t)P.shard_count;
-        xy = (y << 16) | x;
-        pixel = y * (uint32_t)P.width + x;
-        s = chunk * (uint32_t)P.chunk_spp;
-        s_end = s + (uint32_t)P.chunk_spp < (uint32_t)P.spp ? s + (uint32_t)P.chunk_spp : (uint32_t)P.spp;
-        sum = {0.f, 0.f, 0.f};
-        A.cur[sl] = item; A.next[sl] = item + A.n_slots; A.xy[sl] = xy; A.pixel[sl] = pixel; A.s_end[sl] = s_end;
-      }
-    } else {
-      xy = A.xy[sl]; pixel = A.pixel[sl];
-    }
-    if (live) {
-      PathState<float> ps;
-      PathKey key = {pixel, P.seed, s, (uint32_t)P.rng};
-      path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key);
-      A.sample[sl] = s + 1u;     // index of the NEXT sample; the current one is sample - 1
-      A.sum[0][sl] = sum.x; A.sum[1][sl] = sum.y; A.sum[2][sl] = sum.z;
-      A.ray[0][sl] = ps.ray.o.x; A.ray[1][sl] = ps.ray.o.y; A.ray[2][sl] = ps.ray.o.z;
-      A.ray[3][sl] = ps.ray.d.x; A.ray[4][sl] = ps.ray.d.y; A.ray[5][sl] = ps.ray.d.z;
-      A.thr[0][sl] = 1.f; A.thr[1][sl] = 1.f; A.thr[2][sl] = 1.f;
-      A.acc[0][sl] = 0.f; A.acc[1][sl] = 0.f; A.acc[2][sl] = 0.f;
-      A.bsdf_pdf[sl] = 0.f;
-      A.bflags[sl] = F_ALIVE;
-      started = true;
-    }
+  const bool live = sl < A.n_slots;
+  if (live) {
+    const WorkItem it = work_item(P, sl);
+    A.cur[sl] = sl; A.next[sl] = sl + A.n_slots; A.xy[sl] = it.xy; A.pixel[sl] = it.pixel; A.s_end[sl] = it.s_end;
+    PathState<float> ps;
+    PathKey key = {it.pixel, P.seed, it.s_begin, (uint32_t)P.rng};
+    path_begin(ps, cam, P, (int)(it.xy & 0xffffu), (int)(it.xy >> 16), key);
+    A.sample[sl] = it.s_begin + 1u;     // index of the NEXT sample; the current one is sample - 1
+    A.sum[0][sl] = 0.f; A.sum[1][sl] = 0.f; A.sum[2][sl] = 0.f;
+    A.ray[0][sl] = ps.ray.o.x; A.ray[1][sl] = ps.ray.o.y; A.ray[2][sl] = ps.ray.o.z;
+    A.ray[3][sl] = ps.ray.d.x; A.ray[4][sl] = ps.ray.d.y; A.ray[5][sl] = ps.ray.d.z;
+    A.thr[0][sl] = 1.f; A.thr[1][sl] = 1.f; A.thr[2][sl] = 1.f;
+    A.acc[0][sl] = 0.f; A.acc[1][sl] = 0.f; A.acc[2][sl] = 0.f;
+    A.bsdf_pdf[sl] = 0.f;
+    A.bflags[sl] = F_ALIVE;
   }
-  const uint32_t at = block_append(bs, &ctl->n_q[qout], live);
-  if (live) A.q[qout][at] = sl;
-  block_count2(bs, &counters->closest, live, &counters->samples, started);
+  const uint32_t at = block_append(bs, &ctl->n_q[0], live);
+  if (live) A.q[0][at] = sl;
+  block_count2(bs, &counters->closest, live, &counters->samples, live);
 }
 
 // Sort key of a ray: the Morton code of its origin's cell in a 128^3 grid over the tree's bounding box (21 bits) above the
@@ -209,10 +191,10 @@ RTX_DEV uint32_t ray_sort_key(const DScene<float>& sc, V3<float> o, V3<float> d)
 constexpr unsigned kSortKeyBits = 24;
 
 // shadow = 0: the ray queue q (entries = path slots); shadow = 1: the shadow-ray queue (entries = its own indices)
-__global__ __launch_bounds__(256) void wf_sort_keys(DScene<float> sc, WfArrays A, const WfControl* __restrict__ ctl, int q, int shadow, uint32_t bound) {
+__global__ __launch_bounds__(256) void wf_sort_keys(DScene<float> sc, WfArrays A, const WfControl* __restrict__ ctl, int q /* ray queue array */, int nq /* its counter, or the shadow counter */, int shadow, uint32_t bound) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= bound) return;
-  const uint32_t n = shadow ? ctl->n_shadow : ctl->n_q[q];
+  const uint32_t n = shadow ? ctl->n_shadow[nq] : ctl->n_q[nq];
   uint32_t key = 0xffffffffu, entry = 0u;
   if (i < n) {
     if (shadow) {
@@ -270,9 +252,9 @@ RTX_DEV uint32_t feed_take(WaveFeed& f, uint32_t* cursor, bool want, uint32_t n)
 #endif
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int q, int stack_levels, DCounters* counters,
+__global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int nq /* the queue's counter */, int stack_levels, DCounters* counters,
                                                     const uint32_t* __restrict__ order /* the queue's entries in the order to take them */) {
-  const uint32_t n = ctl->n_q[q];
+  const uint32_t n = ctl->n_q[nq];
   uint32_t n_nodes = 0, n_prims = 0;   // node records and leaf records this lane fetched
   WaveFeed feed = {0u, 0u, false};
   LaneStack st = lane_stack(0);
@@ -315,7 +297,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
         if (tree) walk8_begin(w, ray);
         state = 1; have_next = false;
       }
-      const uint32_t e = feed_take(feed, &ctl->cursor, !have_next, n);
+      const uint32_t e = feed_take(feed, &ctl->cursor_rays, !have_next, n);
       if (e != 0xffffffffu) {
         nslot = order[e];
         nray.o = {A.ray[0][nslot], A.ray[1][nslot], A.ray[2][nslot]};
@@ -372,22 +354,32 @@ template <int MODE> RTX_DEV bool wf_load_hit(const DScene<float>& sc, const WfAr
   return true;
 }
 
+// Where a visible light sample's contribution goes: the chunk sum of its slot, or - the path that cast it was the last of its
+// work item, whose sum is already written out - that item's entry of the partial sums.
+constexpr uint32_t kShadowToItem = 0x80000000u;
+
 template <int MODE, bool LDS_MATS, bool NMAP = false>
-__global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DRenderParams P, WfArrays A, WfControl* ctl, int q, DCounters* counters) {
+__global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCamera<float> cam, DRenderParams P, WfArrays A, WfControl* ctl, WfTurn turn,
+                                                   float* __restrict__ partial, DCounters* counters) {
   const DMaterial<float>* mats = sc.mats;
   if constexpr (LDS_MATS) mats = stage_materials(sc);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ BlockScratch bs;
-  if (i == 0) { ctl->cursor = 0u; ctl->n_q[1 - q] = 0u; }   // wf_extend is done with the cursor; the next wf_generate fills the other queue
-  const bool valid = i < ctl->n_q[q];
+  if (i == 0) {   // every kernel of the turn before has finished: its cursors and the counters it read are free
+    ctl->cursor_rays = 0u; ctl->cursor_shadow = 0u;
+    ctl->n_q[turn.n_zero] = 0u; ctl->n_shadow[1 - turn.sh] = 0u;
+  }
+  const bool valid = i < ctl->n_q[turn.n_in];
   uint32_t did = 0;
   bool cast = false;           // a light sample needs its visibility ray
   Ray<float> sh_ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
   float sh_tmax = 0.f;
   V3<float> sh_contrib = {0.f, 0.f, 0.f};
-  uint32_t slot = 0;
+  uint32_t slot = 0, sh_target = 0;
+  bool live = false, started = false;   // the slot has a ray to trace next; it began a new sample
   if (valid) {
-  slot = A.q[q][i];
+  slot = A.q[turn.q_in][i];
+  sh_target = slot;
   PathState<float> ps;
   ps.ray.o = {A.ray[0][slot], A.ray[1][slot], A.ray[2][slot]};
   ps.ray.d = {A.ray[3][slot], A.ray[4][slot], A.ray[5][slot]};
@@ -395,33 +387,67 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DRend
   ps.acc = {A.acc[0][slot], A.acc[1][slot], A.acc[2][slot]};
   ps.bsdf_pdf = A.bsdf_pdf[slot];
   ps.bounce_flags = A.bflags[slot];
-  PathKey key = {A.pixel[slot], P.seed, A.sample[slot] - 1u, (uint32_t)P.rng};
+  const uint32_t pixel = A.pixel[slot], s = A.sample[slot];
+  PathKey key = {pixel, P.seed, s - 1u, (uint32_t)P.rng};
   Hit<float> rec;
   const bool hit = wf_load_hit<MODE>(sc, A, slot, ps.ray, rec);
   did = path_vertex<float, NMAP>(ps, hit, rec, sc, mats, P, key, [&](const Ray<float>& sr, float t_max, V3<float> contrib) {
     cast = true; sh_ray = sr; sh_tmax = t_max; sh_contrib = contrib;
   });
-  A.ray[0][slot] = ps.ray.o.x; A.ray[1][slot] = ps.ray.o.y; A.ray[2][slot] = ps.ray.o.z;
-  A.ray[3][slot] = ps.ray.d.x; A.ray[4][slot] = ps.ray.d.y; A.ray[5][slot] = ps.ray.d.z;
-  A.thr[0][slot] = ps.thr.x; A.thr[1][slot] = ps.thr.y; A.thr[2][slot] = ps.thr.z;
-  A.acc[0][slot] = ps.acc.x; A.acc[1][slot] = ps.acc.y; A.acc[2][slot] = ps.acc.z;
-  A.bsdf_pdf[slot] = ps.bsdf_pdf;
-  A.bflags[slot] = ps.bounce_flags;
+  live = true;
+  if (!(ps.bounce_flags & F_ALIVE)) {
+    // The path ended: it joins the chunk sum, and the slot starts its next sample or takes its next (pixel, chunk) work item.
+    const uint32_t s_end = A.s_end[slot];
+    V3<float> sum = {A.sum[0][slot] + ps.acc.x, A.sum[1][slot] + ps.acc.y, A.sum[2][slot] + ps.acc.z};
+    WorkItem it = {A.xy[slot], pixel, s, s_end};
+    if (s == s_end) {
+      const uint32_t done = A.cur[slot];
+      float* o = partial + (size_t)done * 3u;
+      o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+      sh_target = kShadowToItem | done;
+      sum = {0.f, 0.f, 0.f};
+      const uint32_t item = A.next[slot];
+      if (item >= (uint32_t)P.rows * (uint32_t)P.width * (uint32_t)P.n_chunks) {
+        live = false;
+      } else {
+        it = work_item(P, item);
+        A.cur[slot] = item; A.next[slot] = item + A.n_slots; A.xy[slot] = it.xy; A.pixel[slot] = it.pixel; A.s_end[slot] = it.s_end;
+      }
+    }
+    if (live) {
+      PathKey next_key = {it.pixel, P.seed, it.s_begin, (uint32_t)P.rng};
+      path_begin(ps, cam, P, (int)(it.xy & 0xffffu), (int)(it.xy >> 16), next_key);
+      A.sample[slot] = it.s_begin + 1u;     // index of the NEXT sample; the current one is sample - 1
+      A.sum[0][slot] = sum.x; A.sum[1][slot] = sum.y; A.sum[2][slot] = sum.z;
+      started = true;
+    }
   }
-  const uint32_t k = block_append(bs, &ctl->n_shadow, cast);
+  if (live) {
+    A.ray[0][slot] = ps.ray.o.x; A.ray[1][slot] = ps.ray.o.y; A.ray[2][slot] = ps.ray.o.z;
+    A.ray[3][slot] = ps.ray.d.x; A.ray[4][slot] = ps.ray.d.y; A.ray[5][slot] = ps.ray.d.z;
+    A.thr[0][slot] = ps.thr.x; A.thr[1][slot] = ps.thr.y; A.thr[2][slot] = ps.thr.z;
+    A.acc[0][slot] = ps.acc.x; A.acc[1][slot] = ps.acc.y; A.acc[2][slot] = ps.acc.z;
+    A.bsdf_pdf[slot] = ps.bsdf_pdf;
+    A.bflags[slot] = ps.bounce_flags;
+  }
+  }
+  const uint32_t k = block_append(bs, &ctl->n_shadow[turn.sh], cast);
   if (cast) {
-    A.sh_slot[k] = slot;
+    A.sh_slot[k] = sh_target;
     A.sh[0][k] = sh_ray.o.x; A.sh[1][k] = sh_ray.o.y; A.sh[2][k] = sh_ray.o.z;
     A.sh[3][k] = sh_ray.d.x; A.sh[4][k] = sh_ray.d.y; A.sh[5][k] = sh_ray.d.z; A.sh[6][k] = sh_tmax;
     A.sh_c[0][k] = sh_contrib.x; A.sh_c[1][k] = sh_contrib.y; A.sh_c[2][k] = sh_contrib.z;
   }
+  const uint32_t at = block_append(bs, &ctl->n_q[turn.n_out], live);
+  if (live) A.q[turn.q_out][at] = slot;
   block_count2(bs, &counters->segments, (did & STEP_SHADED) != 0, &counters->shadow, (did & STEP_SHADOW) != 0);
+  block_count2(bs, &counters->closest, live, &counters->samples, started);
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int stack_levels,
+__global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int sh /* the shadow queue's counter */, float* __restrict__ partial, int stack_levels,
                                                      const uint32_t* __restrict__ order /* shadow-queue indices in the order to take them, or NULL = as queued */) {
-  const uint32_t n = ctl->n_shadow;
+  const uint32_t n = ctl->n_shadow[sh];
   WaveFeed feed = {0u, 0u, false};
   LaneStack st = lane_stack(0);
   const bool tree = MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims;
@@ -441,8 +467,13 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<
     const int walking = __popcll(__ballot(state == 1));
     if (64 - walking >= RTX_REFILL_IDLE || walking == 0) {
       if (state == 3) {
-        const uint32_t slot = A.sh_slot[i];   // at most one shadow ray per slot per iteration: no atomics needed
-        A.acc[0][slot] += A.sh_c[0][i]; A.acc[1][slot] += A.sh_c[1][i]; A.acc[2][slot] += A.sh_c[2][i];
+        const uint32_t to = A.sh_slot[i];   // at most one shadow ray per slot (and per finished work item) per turn: no atomics needed
+        if (to & kShadowToItem) {
+          float* o = partial + (size_t)(to & ~kShadowToItem) * 3u;
+          o[0] += A.sh_c[0][i]; o[1] += A.sh_c[1][i]; o[2] += A.sh_c[2][i];
+        } else {
+          A.sum[0][to] += A.sh_c[0][i]; A.sum[1][to] += A.sh_c[1][i]; A.sum[2][to] += A.sh_c[2][i];
+        }
       }
       if (state != 1) state = 0;
       if (state == 0 && have_next) {
@@ -451,7 +482,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<
         if (tree) walk8_begin(w, sr);
         state = 1; have_next = false;
       }
-      const uint32_t e = feed_take(feed, &ctl->cursor, !have_next, n);
+      const uint32_t e = feed_take(feed, &ctl->cursor_shadow, !have_next, n);
       if (e != 0xffffffffu) {
         ni = order ? order[e] : e;
         nsr.o = {A.sh[0][ni], A.sh[1][ni], A.sh[2][ni]};
@@ -477,39 +508,41 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<
   }
 }
 
-template <int MODE> void launch_iteration_kernels(const DScene<float>& sc_in, const DCamera<float>& cam, const DRenderParams& P, const WfArrays& A, WfControl* ctl,
-                                                  float* partial, DCounters* counters, bool lds_mats, size_t mat_lds, int stack_levels, unsigned grid,
-                                                  unsigned resident_blocks, int step /*0 first generate, 1 shade, 2 connect, 3 generate*/, int qa, int qb,
-                                                  hipStream_t stream, uint32_t& launches, WavefrontPool& pool) {
-  const DScene<float>& sc = sc_in;
+template <int MODE> void launch_turn_kernels(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, const WfArrays& A, WfControl* ctl,
+                                             float* partial, DCounters* counters, bool lds_mats, size_t mat_lds, int stack_levels, unsigned grid,
+                                             unsigned resident_blocks, const WfTurn* turn /* NULL: the start of a render */, hipStream_t stream, uint32_t& launches,
+                                             WavefrontPool& pool) {
   const dim3 g((grid + (kStreamBlock / kBlock) - 1) / (kStreamBlock / kBlock)), bs(kStreamBlock), b(kBlock);   // `grid` counts kBlock-sized groups
   const dim3 gw(grid < resident_blocks ? grid : resident_blocks);   // persistent traversal kernels
   const size_t walk_lds = MODE == MODE_FLAT ? 0 : (size_t)stack_levels * kBlock * sizeof(int);
   const bool sorted = pool.sort_rays && MODE != MODE_FLAT && sc.n_nodes8 > 0;
   const uint32_t bound = grid * (unsigned)kBlock < A.n_slots ? grid * (unsigned)kBlock : A.n_slots;   // the queues are no longer than this
-  auto sort_queue = [&](int q, int shadow) {
-    hipLaunchKernelGGL(wf_sort_keys, dim3((bound + 255) / 256), dim3(256), 0, stream, sc, A, ctl, q, shadow, bound);
+  auto sort_queue = [&](int q, int nq, int shadow) {
+    hipLaunchKernelGGL(wf_sort_keys, dim3((bound + 255) / 256), dim3(256), 0, stream, sc, A, ctl, q, nq, shadow, bound);
     size_t bytes = pool.sort_tmp.cap;
     (void)rocprim::radix_sort_pairs(pool.sort_tmp.ptr, bytes, A.key_in, A.key_out, A.order_in, A.order_out, (size_t)bound, 0u, kSortKeyBits, stream);
     launches += 2;
   };
-  if (step == 0 || step == 3) {
-    hipLaunchKernelGGL(wf_generate, g, bs, 0, stream, cam, P, A, ctl, step == 0 ? 1 : 0, qa, qb, partial, counters);
-    if (sorted) sort_queue(qb, 0);
-    pool.mark(stream);
-    hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, qb, stack_levels, counters, sorted ? A.order_out : A.q[qb]);
-    pool.mark(stream);
+  int q_out = 0, n_out = 0;
+  if (!turn) {
+    hipLaunchKernelGGL(wf_start, g, bs, 0, stream, cam, P, A, ctl, counters);
     ++launches;
-  } else if (step == 1) {
-    if (MODE == MODE_TREE_UV && sc.n_nmaps > 0) {   // the instances that apply normal maps
-      if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true, MODE == MODE_TREE_UV>), g, bs, mat_lds, stream, sc, P, A, ctl, qa, counters);
-      else hipLaunchKernelGGL((wf_shade<MODE, false, MODE == MODE_TREE_UV>), g, bs, 0, stream, sc, P, A, ctl, qa, counters);
-    } else if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, P, A, ctl, qa, counters);
-    else hipLaunchKernelGGL((wf_shade<MODE, false>), g, bs, 0, stream, sc, P, A, ctl, qa, counters);
   } else {
-    if (sorted) sort_queue(0, 1);
-    hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, stack_levels, sorted ? A.order_out : nullptr);
+    q_out = turn->q_out; n_out = turn->n_out;
+    if (MODE == MODE_TREE_UV && sc.n_nmaps > 0) {   // the instances that apply normal maps
+      if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true, MODE == MODE_TREE_UV>), g, bs, mat_lds, stream, sc, cam, P, A, ctl, *turn, partial, counters);
+      else hipLaunchKernelGGL((wf_shade<MODE, false, MODE == MODE_TREE_UV>), g, bs, 0, stream, sc, cam, P, A, ctl, *turn, partial, counters);
+    } else if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, cam, P, A, ctl, *turn, partial, counters);
+    else hipLaunchKernelGGL((wf_shade<MODE, false>), g, bs, 0, stream, sc, cam, P, A, ctl, *turn, partial, counters);
+    if (sorted) sort_queue(0, turn->sh, 1);
+    hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, turn->sh, partial, stack_levels, sorted ? A.order_out : nullptr);
+    launches += 2;
   }
+  if (sorted) sort_queue(q_out, n_out, 0);
+  pool.mark(stream);
+  hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, n_out, stack_levels, counters, sorted ? A.order_out : A.q[q_out]);
+  pool.mark(stream);
+  ++launches;
 }
 
 // Blocks of the traversal kernels one CU keeps resident (the smaller of the two kernels' figures).
@@ -574,26 +607,22 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
                                                                                                        : walk_blocks_per_cu<MODE_TREE_UV>(stack_levels);
   const unsigned resident = (unsigned)n_cus * (unsigned)per_cu;
 
-  auto run = [&](int step, int qa, int qb, unsigned grid) {
-    if (mode == MODE_FLAT) launch_iteration_kernels<MODE_FLAT>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, pool);
-    else if (mode == MODE_TREE) launch_iteration_kernels<MODE_TREE>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, pool);
-    else launch_iteration_kernels<MODE_TREE_UV>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, step, qa, qb, stream, launches, pool);
-    ++launches;
+  auto run = [&](const WfTurn* turn, unsigned grid) {
+    if (mode == MODE_FLAT) launch_turn_kernels<MODE_FLAT>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, turn, stream, launches, pool);
+    else if (mode == MODE_TREE) launch_turn_kernels<MODE_TREE>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, turn, stream, launches, pool);
+    else launch_turn_kernels<MODE_TREE_UV>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, turn, stream, launches, pool);
   };
   if (hipMemsetAsync(ctl, 0, sizeof(WfControl), stream) != hipSuccess) { err = "memset"; return RTX_ERR_HIP; }
   pool.events_used = 0;
   unsigned live_bound = n_slots;   // upper bound of the ray queue length (it only shrinks)
   unsigned grid = (live_bound + kBlock - 1) / kBlock;
-  run(0, 0, 0, grid);
-  int cur = 0;
+  run(nullptr, grid);
   for (unsigned iter = 0;; ++iter) {
-    run(1, cur, 0, grid);
-    run(2, 0, 0, grid);
-    run(3, cur, 1 - cur, grid);
-    cur = 1 - cur;
+    const WfTurn turn = {(int)(iter & 1u), (int)((iter + 1u) & 1u), (int)(iter % 3u), (int)((iter + 1u) % 3u), (int)((iter + 2u) % 3u), (int)(iter & 1u)};
+    run(&turn, grid);
     if ((iter & 7u) == 7u || live_bound < 65536u) {
       uint32_t n_live = 0;
-      if (hipMemcpyAsync(&n_live, &ctl->n_q[cur], sizeof n_live, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      if (hipMemcpyAsync(&n_live, &ctl->n_q[turn.n_out], sizeof n_live, hipMemcpyDeviceToHost, stream) != hipSuccess ||
           hipStreamSynchronize(stream) != hipSuccess) { err = hipGetErrorString(hipGetLastError()); return RTX_ERR_HIP; }
       if (n_live == 0) break;
       live_bound = n_live;
