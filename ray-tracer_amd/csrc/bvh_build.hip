@@ -155,9 +155,8 @@ __global__ __launch_bounds__(256) void split_level_kernel(const uint64_t* __rest
   const int n_leaf = n - n_inner;
   const int ib = n_inner ? (int)atomicAdd(&ctr->nodes, (uint32_t)n_inner) : 0;
   const int lb = n_leaf ? (int)atomicAdd(&ctr->leaves, (uint32_t)n_leaf) : 0;
-  // the children's records: the inner children's node records (one unit each), padded to an even count, then the leaf
-  // records (two units each): every block starts on an even unit, so that a leaf record is one 128-byte line
-  const int ub = (int)atomicAdd(&ctr->units, (uint32_t)(((n_inner + 1) & ~1) + 2 * n_leaf));
+  // the children's records, one unit each: the inner children's node records, then the leaf records
+  const int ub = (int)atomicAdd(&ctr->units, (uint32_t)n);
   int ki = 0, kl = 0;
   for (int i = 0; i < n; ++i) {
     if (re[i] - rb[i] > kLeafMaxPrims) { unit_of[ib + ki] = ub + ki; range[ib + ki++] = make_int2(rb[i], re[i]); }
@@ -186,24 +185,25 @@ __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, c
     } else if (s < m.n_inner + m.n_leaf) {
       const int l = m.leaf_base + (s - m.n_inner);
       const int2 lr = leaf_range[l];
-      DLeaf3 rec;
-      for (int k = 0; k < 3; ++k) { for (int j = 0; j < 9; ++j) rec.v[k][j] = NAN; rec.id[k] = -1; }
-      rec.count = lr.y; rec.other = 0u;
-      for (int k = 0; k < lr.y; ++k) {
-        const int p = (int)order[lr.x + k];
+      DLeaf rec;
+      for (int j = 0; j < 9; ++j) rec.v[j] = NAN;
+      rec.ref = -1;
+      for (int j = 0; j < 6; ++j) rec.pad[j] = 0;
+      if (lr.y > 0) {
+        const int p = (int)order[lr.x];
         const float4 a = plo[p], b = phi[p];
-        rec.id[k] = p;
-        if (!(a.x <= b.x)) continue;   // an unhittable primitive keeps its slot, with NaN vertices
-        clo[0] = fminf(clo[0], a.x); clo[1] = fminf(clo[1], a.y); clo[2] = fminf(clo[2], a.z);
-        chi[0] = fmaxf(chi[0], b.x); chi[1] = fmaxf(chi[1], b.y); chi[2] = fmaxf(chi[2], b.z);
-        if (p >= ns && p < ns + nt) {
-          const DTri<float>& t = tris[p - ns];
-          for (int j = 0; j < 3; ++j) { rec.v[k][j] = t.v0[j]; rec.v[k][3 + j] = t.v1[j]; rec.v[k][6 + j] = t.v2[j]; }
-        } else {
-          rec.other |= 1u << k;
+        if (a.x <= b.x) {   // (an unhittable primitive keeps its record, with nothing to test)
+          clo[0] = a.x; clo[1] = a.y; clo[2] = a.z; chi[0] = b.x; chi[1] = b.y; chi[2] = b.z;
+          if (p >= ns && p < ns + nt) {
+            const DTri<float>& t = tris[p - ns];
+            for (int j = 0; j < 3; ++j) { rec.v[j] = t.v0[j]; rec.v[3 + j] = t.v1[j]; rec.v[6 + j] = t.v2[j]; }
+            rec.ref = p;
+          } else {
+            rec.ref = -2 - p;
+          }
         }
       }
-      *reinterpret_cast<DLeaf3*>(units + m.unit_base + ((m.n_inner + 1) & ~1) + 2 * (s - m.n_inner)) = rec;
+      *reinterpret_cast<DLeaf*>(units + m.unit_base + s) = rec;
     }
   }
   float lo[3], hi[3];

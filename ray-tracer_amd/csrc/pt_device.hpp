@@ -426,7 +426,7 @@ RTX_DEV int walk8_pop(Walk8& w, LaneStack st) {
   const int slot = (int)(pk & 7u), cnt = (int)((pk >> 24) & 7u), ni = (int)(pk >> 28);
   if (cnt <= 1) --w.sp;
   else st.put(e + 1, (int)(((pk & 0x00ffffffu) >> 3) | ((uint32_t)(cnt - 1) << 24) | (pk & 0xf0000000u)));
-  return slot < ni ? ib + slot : ~(ib + ((ni + 1) & ~1) + 2 * (slot - ni));   // the leaf records follow the inner children from the next even unit
+  return slot < ni ? ib + slot : ~(ib + slot);   // child k's record is unit inner_base + k; the leaf records follow the inner children
 }
 
 // SORTED = false (any-hit queries): the children entered are visited in slot order, the sorting network is left out.
@@ -451,7 +451,7 @@ template <bool SORTED = true> RTX_DEV void walk8_inner(const DScene<float>& sc, 
   const uint32_t ny[2] = {uy ? h1.z : h3.x, uy ? h1.w : h3.y}, fy[2] = {uy ? h3.x : h1.z, uy ? h3.y : h1.w};
   const uint32_t nz[2] = {uz ? h2.x : h3.z, uz ? h2.y : h3.w}, fz[2] = {uz ? h3.z : h2.x, uz ? h3.w : h2.y};
   const int n_inner = (int)((exps >> 24) & 15u);
-  const int inner_base = (int)h0.w, leaf_base = inner_base + ((n_inner + 1) & ~1) - 2 * n_inner;   // child k >= n_inner is the leaf record at unit leaf_base + 2 k
+  const int inner_base = (int)h0.w;   // child k's record is unit inner_base + k (k >= n_inner: a leaf record)
   uint32_t key[8];
   int m = 0;   // children entered
 #pragma unroll
@@ -478,7 +478,7 @@ template <bool SORTED = true> RTX_DEV void walk8_inner(const DScene<float>& sc, 
       st.put(e, inner_base); st.put(e + 1, (int)((slots >> 3) | ((uint32_t)(m - 1) << 24) | ((uint32_t)n_inner << 28)));
       ++w.sp;
     }
-    if (m >= 1) { const int k = (int)(slots & 7u); w.node = k < n_inner ? inner_base + k : ~(leaf_base + 2 * k); }
+    if (m >= 1) { const int k = (int)(slots & 7u); w.node = k < n_inner ? inner_base + k : ~(inner_base + k); }
     else w.node = walk8_pop(w, st);
     return;
   }
@@ -499,7 +499,7 @@ template <bool SORTED = true> RTX_DEV void walk8_inner(const DScene<float>& sc, 
     st.put(e, inner_base); st.put(e + 1, (int)(slots | ((uint32_t)(m - 1) << 24) | ((uint32_t)n_inner << 28)));
     ++w.sp;
   }
-  if (m >= 1) { const int k = (int)(key[0] & 7u); w.node = k < n_inner ? inner_base + k : ~(leaf_base + 2 * k); }
+  if (m >= 1) { const int k = (int)(key[0] & 7u); w.node = k < n_inner ? inner_base + k : ~(inner_base + k); }
   else w.node = walk8_pop(w, st);
 }
 
@@ -518,28 +518,20 @@ RTX_DEV bool leaf_tri_t(const float* v, const Ray<float>& r, float t_min, float 
   return fabsf(a) >= 1e-8f && u >= 0.f && u <= 1.f && vv >= 0.f && u + vv <= 1.f && t >= t_min && t <= t_max;
 }
 
-// Tests the primitives of the leaf record with code `leaf` (a ~unit) against the ray; updates the candidate and the tie state.
+// Tests the primitive of the leaf record with code `leaf` (a ~unit) against the ray; updates the candidate and the tie state.
 RTX_DEV void walk8_leaf_test(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, Walk8& w, int leaf) {
-  const DLeaf3* lf = reinterpret_cast<const DLeaf3*>(sc.nodes8 + (~leaf));
-  const uint4* rec = reinterpret_cast<const uint4*>(lf);
-  uint4 q[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) q[i] = rec[i];
-  const float* v = reinterpret_cast<const float*>(q);
-  const int* tail = reinterpret_cast<const int*>(q) + 27;   // id[3], count, other
-#pragma unroll
-  for (int k = 0; k < kLeafMaxPrims; ++k) {
-    float t, u, vv;
-    bool ok = leaf_tri_t(v + 9 * k, r, t_min, c.t, t, u, vv);
-    const int p = tail[k];
-    if (ok && t == c.t && w.best_p >= 0) ok = sc.rank[p] > sc.rank[w.best_p];   // exact tie: the later one in the reference's order wins
-    if (ok) { c.t = t; c.type = PRIM_TRIANGLE; c.idx = p - sc.n_spheres; c.uv_kind = 1; c.ua = u; c.ub = vv; w.best_p = p; }
-  }
-  uint32_t other = (uint32_t)tail[4];
-  while (other) {   // spheres and boxes: rare in a tree of triangles
-    const int k = __ffs((int)other) - 1;
-    other &= other - 1u;
-    const int p = k == 0 ? tail[0] : (k == 1 ? tail[1] : tail[2]);   // (no run-time index into the record: it stays in registers)
+  const uint4* rec = reinterpret_cast<const uint4*>(sc.nodes8 + (~leaf));
+  const uint4 q0 = rec[0], q1 = rec[1];
+  const uint2 q2 = *reinterpret_cast<const uint2*>(rec + 2);
+  const float v[9] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w), __uint_as_float(q1.x),
+                      __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
+  const int ref = (int)q2.y;
+  float t, u, vv;
+  bool ok = leaf_tri_t(v, r, t_min, c.t, t, u, vv);
+  if (ok && t == c.t && w.best_p >= 0) ok = sc.rank[ref] > sc.rank[w.best_p];   // exact tie: the later one in the reference's order wins
+  if (ok) { c.t = t; c.type = PRIM_TRIANGLE; c.idx = ref - sc.n_spheres; c.uv_kind = 1; c.ua = u; c.ub = vv; w.best_p = ref; }
+  if (ref < -1) {   // a sphere or a box: rare in a tree of triangles
+    const int p = -2 - ref;
     const int type = p < sc.n_spheres ? PRIM_SPHERE : PRIM_BOX;
     const int idx = p < sc.n_spheres ? p : p - sc.n_spheres - sc.n_tris;
     Cand<float> trial = c;

@@ -57,16 +57,17 @@ struct alignas(64) DNode8 {
 };
 static_assert(sizeof(DNode8) == 64, "node record");
 constexpr int kNodeOriginBits = 21;
-// One leaf record is one 128-byte line: up to three triangles with their vertices in place.  id = the primitive's number in
-// the reference's primitive list (spheres, then triangles, then boxes: engine/scene.hpp:496-533), -1 for an empty slot.  A
-// slot that holds a sphere or a box (bit k of `other`) or nothing has NaN vertices, which fail the triangle test.
-struct alignas(128) DLeaf3 {
-  float v[3][9];
-  int32_t id[3];
-  int32_t count;
-  uint32_t other;
+// One leaf record is one unit: ONE primitive.  ref >= 0: a triangle with its vertices in place, ref = the primitive's number in
+// the reference's primitive list (spheres, then triangles, then boxes: engine/scene.hpp:496-533); ref == -1: nothing to test (a
+// primitive the reference can never hit); ref <= -2: a sphere or a box, primitive number -2 - ref, tested through its table.  A
+// record without a triangle has NaN vertices, which fail the triangle test.
+struct alignas(64) DLeaf {
+  float v[9];
+  int32_t ref;
+  int32_t pad[6];
 };
-constexpr int kLeafMaxPrims = 3;
+static_assert(sizeof(DLeaf) == 64, "leaf record");
+constexpr int kLeafMaxPrims = 1;
 constexpr int kWalkDone = 0x7fffffff;
 // Words of stack a walk of a tree of `levels` node levels can need: one three-word entry per level, and one to spare.
 constexpr int walk_stack_slots(int levels) { return 2 * (levels + 1); }
@@ -95,7 +96,7 @@ template <class R> struct DScene {
   const DImage* images; const int32_t* emissive;   // indices of emissive spheres, ascending
   const DNode2<R>* nodes; const DPrimRef* prims;    // production BVH + primitive order (reference leaf order)
   const DNode8* nodes8;                                // single-precision traversal layout: 64-byte units, node records and (two units each) leaf records (NULL in the double scene and for scenes tested linearly)
-  const int32_t* rank;                                 // position of every bounded primitive (numbered as DLeaf3::id) in the reference's leaf order
+  const int32_t* rank;                                 // position of every bounded primitive (numbered as in DLeaf::ref) in the reference's leaf order
   const DFlatRec* flat;                                // flat scenes only (single precision)
   float bb_lo[3], bb_scale[3];                         // the eight-wide tree's root box as a 128^3 grid: cell = (p - bb_lo) * bb_scale (ray sorting)
   float wt_anchor[3], wt_step[3];                      // the grid the node origins of the eight-wide tree lie on (DNode8::org)

@@ -423,7 +423,7 @@ int rtx_get_bvh_info(rtx_ctx* c, rtx_bvh_info* out) {
   out->wide_leaves = (uint64_t)c->scene.wide.n_leaves; out->wide_levels = (uint64_t)c->scene.wide.levels;
   out->wide_build_seconds = c->scene.wide.seconds;
   out->build_seconds = c->scene.build_seconds;
-  out->leaf_bytes = c->scene.wide.n_nodes > 0 ? sizeof(DLeaf3) : 0;
+  out->leaf_bytes = c->scene.wide.n_nodes > 0 ? sizeof(DLeaf) : 0;
   return RTX_OK;
 }
 
