@@ -263,7 +263,7 @@ typedef struct rtx_bvh_info {
   uint64_t ref_nodes, ref_prims;   /* the reference-order binary tree (validation entry point, double precision, tie ranks) */
   uint64_t wide_nodes, wide_bytes; /* node records of the eight-wide tree the single-precision integrator walks, and their total size */
   double build_seconds;            /* host time of the reference-order build */
-  uint64_t leaf_bytes;             /* size of one leaf record of the eight-wide tree (up to three primitives) */
+  uint64_t leaf_bytes;             /* size of one leaf record of the eight-wide tree (one primitive) */
   uint64_t wide_leaves;            /* its leaf records */
   uint64_t wide_levels;            /* its depth in node levels */
   double wide_build_seconds;       /* time of its build on the GPU */

@@ -1,4 +1,4 @@
-// GPU construction of the eight-wide traversal tree of the single-precision kernels (DNode8 / DLeaf3, pt_types.hpp).
+// GPU construction of the eight-wide traversal tree of the single-precision kernels (DNode8 / DLeaf, pt_types.hpp).
 //
 // The reference builds its BVH on one host thread by recursive median splits (ref: engine/bvh.hpp:148-218); that tree is still
 // built on the host for the validation entry point and for the tie ranks.  The tree the integrator walks is built here, in a
@@ -10,7 +10,7 @@
 //   3. radix sort           (rocPRIM) primitives in Morton order
 //   4. split_level_kernel   top-down, one launch per level: a node takes its range of the sorted order and cuts it at the highest
 //                           differing code bit (Karras 2012), always the largest remaining piece, until it has eight children or
-//                           every piece fits a leaf (three primitives = one 128-byte record)
+//                           every piece is a single primitive (one leaf record)
 //   5. emit_level_kernel    bottom-up, one launch per level: eight lanes per node gather the children's boxes (writing the leaf
 //                           records on the way), reduce the node's box and quantise the children against it, rounding outward
 //
@@ -312,8 +312,8 @@ int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& ou
     if (level_first.size() > 200) { err = "tree build: too many levels"; return RTX_ERR_HIP; }
   }
   const int n_nodes = (int)hc.nodes, n_leaves = (int)hc.leaves, levels = (int)level_first.size() - 1;
-  // one array of 64-byte units holds the node records (one unit) and the leaf records (two units); eight spare leaf records of
-  // zeros behind it (three degenerate triangles each, nothing to hit): a node whose box is a single point cannot keep rays out
+  // one array of 64-byte units holds the node records and the leaf records; sixteen spare records of zeros behind it (degenerate
+  // triangles, nothing to hit): a node whose box is a single point cannot keep rays out
   // of its unused slots, such a slot then reads a neighbouring record or one of these
   const size_t n_units = (size_t)hc.units + 16;
   if (n_units > 0x7fffffffull) { err = "tree build: more than 2^31 record units"; return RTX_ERR_UNSUPPORTED; }

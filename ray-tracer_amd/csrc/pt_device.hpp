@@ -389,12 +389,12 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
 }
 
 // ------------------------------------------------------------------------------------------
-// Single-precision walk over the eight-wide tree (DNode8 / DLeaf3, pt_types.hpp), cut into resumable steps so that the
+// Single-precision walk over the eight-wide tree (DNode8 / DLeaf, pt_types.hpp), cut into resumable steps so that the
 // lanes of a persistent kernel can pick up a new ray when theirs is finished.
 //   walk8_inner  fetches ONE node record (64 bytes), tests its eight quantised boxes, continues with the nearest
 //                child entered and parks the others, nearest first, as ONE stack entry;
-//   walk8_leaf   fetches ONE leaf record (a 128-byte line) and tests its up to three triangles (spheres and boxes through
-//                their tables).
+//   walk8_leaf   fetches ONE leaf record and tests its primitive (a triangle in place; a sphere or a box through its
+//                table).
 // w.node is a node record's unit (>= 0), a leaf code ~unit (< 0) or kWalkDone.  A stack entry is the group of siblings still to
 // visit under one node, two words: the node's inner_base (where its children's records start), and  slots (3 bits each, next first) | remaining
 // count << 24 | n_inner << 28;  a child's code follows from its slot.  One entry per level at most, so levels + 1 entries always
@@ -527,13 +527,16 @@ RTX_DEV void walk8_leaf_test(const DScene<float>& sc, const Ray<float>& r, float
                       __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
   const int ref = (int)q2.y;
   float t, u, vv;
-  bool ok = leaf_tri_t(v, r, t_min, c.t, t, u, vv);
+  // (the range checks on ref cost two instructions: a node whose box is a single point cannot keep rays out of its unused slots,
+  // and such a slot reads whatever record follows the node's children)
+  bool ok = leaf_tri_t(v, r, t_min, c.t, t, u, vv) && (uint32_t)(ref - sc.n_spheres) < (uint32_t)sc.n_tris;
   if (ok && t == c.t && w.best_p >= 0) ok = sc.rank[ref] > sc.rank[w.best_p];   // exact tie: the later one in the reference's order wins
   if (ok) { c.t = t; c.type = PRIM_TRIANGLE; c.idx = ref - sc.n_spheres; c.uv_kind = 1; c.ua = u; c.ub = vv; w.best_p = ref; }
-  if (ref < -1) {   // a sphere or a box: rare in a tree of triangles
-    const int p = -2 - ref;
-    const int type = p < sc.n_spheres ? PRIM_SPHERE : PRIM_BOX;
-    const int idx = p < sc.n_spheres ? p : p - sc.n_spheres - sc.n_tris;
+  const int p = -2 - ref;
+  const bool sphere = (uint32_t)p < (uint32_t)sc.n_spheres, box = (uint32_t)(p - sc.n_spheres - sc.n_tris) < (uint32_t)sc.n_boxes;
+  if (ref < -1 && (sphere || box)) {   // rare in a tree of triangles
+    const int type = sphere ? PRIM_SPHERE : PRIM_BOX;
+    const int idx = sphere ? p : p - sc.n_spheres - sc.n_tris;
     Cand<float> trial = c;
     test_bounded(sc, type, idx, r, t_min, trial);
     const bool changed = trial.type == type && trial.idx == idx && (trial.t != c.t || c.type != type || c.idx != idx);

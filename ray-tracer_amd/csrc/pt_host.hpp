@@ -43,7 +43,7 @@ struct HostBvh {
 
 // The eight-wide tree of the single-precision kernels, built on the GPU (bvh_build.hip).
 struct WideTree {
-  DeviceBuffer nodes;           // one array of 64-byte units: DNode8 records (one unit) and DLeaf3 records (two units, even-aligned)
+  DeviceBuffer nodes;           // one array of 64-byte units: DNode8 and DLeaf records
   size_t n_units = 0;
   int n_nodes = 0, n_leaves = 0, levels = 0;
   float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};   // the root's box

@@ -44,8 +44,8 @@ template <class R> struct DNode2 { R lo[3], hi[3]; int32_t a, count; };
 // Compressed Wide BVHs", HPG 2017).  The origin is itself a point of a 2^21-step grid over the scene's bounds
 // (DScene::wt_anchor + u * DScene::wt_step per axis, evaluated with one fmaf exactly as the builder evaluated it), three 21-bit
 // numbers in two words.  Node and leaf records share one array of 64-byte units.  The records of a node's children form one
-// block that starts at unit inner_base (an even unit): children 0 .. n_inner-1 are the node records inner_base + k; after
-// them, from the next even unit on, children n_inner .. n_child-1 are leaf records of two units each (128-byte aligned).
+// block: child k's record is unit inner_base + k; children 0 .. n_inner-1 are node records, children n_inner .. n_child-1 leaf
+// records.
 // Unused slots hold planes (255, 0), an interval no ray enters (the traversal picks near and far planes by the ray's
 // direction, it does not order them).
 struct alignas(64) DNode8 {
@@ -95,7 +95,7 @@ template <class R> struct DScene {
   const DPoint<R>* points; const DQuad<R>* quads; const DDisk<R>* disks; const DMaterial<R>* mats;
   const DImage* images; const int32_t* emissive;   // indices of emissive spheres, ascending
   const DNode2<R>* nodes; const DPrimRef* prims;    // production BVH + primitive order (reference leaf order)
-  const DNode8* nodes8;                                // single-precision traversal layout: 64-byte units, node records and (two units each) leaf records (NULL in the double scene and for scenes tested linearly)
+  const DNode8* nodes8;                                // single-precision traversal layout: 64-byte units, node records and leaf records (NULL in the double scene and for scenes tested linearly)
   const int32_t* rank;                                 // position of every bounded primitive (numbered as in DLeaf::ref) in the reference's leaf order
   const DFlatRec* flat;                                // flat scenes only (single precision)
   float bb_lo[3], bb_scale[3];                         // the eight-wide tree's root box as a 128^3 grid: cell = (p - bb_lo) * bb_scale (ray sorting)
