@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
           Hit<float> h;   // flat scenes: the candidate is cheap to redo in the shade kernel; keep t + id
           if (flat_closest(sc, ray, 0.001f, 1e9f, h)) { id = (h.type << 24) | h.idx; t = h.t; }
         } else {
-          test_unbounded(sc, ray, 0.001f, c);
+          if (!tree) test_unbounded(sc, ray, 0.001f, c);   // (after a tree walk, wf_shade tests the planes and lights: every lane is busy there)
           if (c.type >= 0) { id = (c.type << 24) | c.idx; t = c.t; ua = c.ua; ub = c.ub; uv = (c.uv_kind << 24) | (c.uv_idx & 0xffffff); }
         }
         A.hit_t[slot] = t; A.hit_id[slot] = id;
@@ -338,19 +338,26 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
   }
 }
 
-// Rebuild the Hit of a stored candidate (point, normal, face, material, u/v).
+// Rebuild the Hit of a stored candidate (point, normal, face, material, u/v).  After a tree walk the candidate is the nearest
+// BOUNDED primitive only: the planes and lights (the linear tail of Scene::hit, engine/scene.hpp:640-672) are tested here, against
+// the interval that candidate leaves.
 template <int MODE> RTX_DEV bool wf_load_hit(const DScene<float>& sc, const WfArrays& A, uint32_t slot, const Ray<float>& ray, Hit<float>& h) {
   const int id = A.hit_id[slot];
-  if (id < 0) return false;
+  const bool tree = MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims;
+  if (id < 0 && !tree) return false;
   Cand<float> c;
-  c.t = A.hit_t[slot]; c.type = id >> 24; c.idx = id & 0xffffff; c.ua = 0.f; c.ub = 0.f; c.uv_kind = 0; c.uv_idx = -1;
+  cand_init(c, 1e9f);
+  if (id >= 0) { c.t = A.hit_t[slot]; c.type = id >> 24; c.idx = id & 0xffffff; }
   if constexpr (MODE == MODE_TREE_UV) {
-    const int uv = A.hit_uv[slot];
-    c.ua = A.hit_ua[slot]; c.ub = A.hit_ub[slot]; c.uv_kind = uv >> 24; c.uv_idx = uv & 0xffffff;
-    finalize_hit<float, true>(sc, ray, c, h);
-  } else {
-    finalize_hit<float, false>(sc, ray, c, h);
+    if (id >= 0) {
+      const int uv = A.hit_uv[slot];
+      c.ua = A.hit_ua[slot]; c.ub = A.hit_ub[slot]; c.uv_kind = uv >> 24; c.uv_idx = uv & 0xffffff;
+    }
   }
+  if (tree) test_unbounded(sc, ray, 0.001f, c);
+  if (c.type < 0) return false;
+  if constexpr (MODE == MODE_TREE_UV) finalize_hit<float, true>(sc, ray, c, h);
+  else finalize_hit<float, false>(sc, ray, c, h);
   return true;
 }
 
@@ -394,6 +401,8 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
   did = path_vertex<float, NMAP>(ps, hit, rec, sc, mats, P, key, [&](const Ray<float>& sr, float t_max, V3<float> contrib) {
     cast = true; sh_ray = sr; sh_tmax = t_max; sh_contrib = contrib;
   });
+  // a light sample behind a plane or a light needs no walk (wf_connect tests the tree only)
+  if (cast && MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims && occluded_unbounded(sc, sh_ray, 0.001f, sh_tmax)) cast = false;
   live = true;
   if (!(ps.bounce_flags & F_ALIVE)) {
     // The path ended: it joins the chunk sum, and the slot starts its next sample or takes its next (pixel, chunk) work item.
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<
       if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
         if (leaf) walk8_leaf<true>(sc, sr, 0.001f, c, w, st);
       }
-      if (state == 1 && w.node == kWalkDone) state = (c.type >= 0 || occluded_unbounded(sc, sr, 0.001f, t_max)) ? 2 : 3;
+      if (state == 1 && w.node == kWalkDone) state = c.type >= 0 ? 2 : 3;   // (wf_shade has tested the planes and lights)
     }
   }
 }
