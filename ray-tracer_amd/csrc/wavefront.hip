@@ -56,11 +56,11 @@ struct WfControl { uint32_t n_q[3]; uint32_t n_shadow[2]; uint32_t cursor_rays, 
 // its shadow rays are counted in n_shadow[sh] (it clears the other one).
 struct WfTurn { int q_in, q_out, n_in, n_out, n_zero, sh; };
 
-// A persistent traversal wave runs the leaf phase when at least this many lanes have a leaf pending (or none has a node).
-// A leaf phase costs about as many instructions as a node phase and, one leaf per four nodes, serves a fifth of the lanes:
-// measured on the 10 M-triangle scene (closest-hit kernel, 64 spp): 2: 299 ms, 8: 290, 16: 289, 24: 296.
+// A persistent traversal wave runs its leaf step when at least this many lanes have a leaf record pending (or none has a node).
+// With one primitive per leaf record the step is short, and waiting for company does not pay: measured on the 10 M-triangle scene
+// (closest-hit kernel, 64 spp): 1: 223.7 ms, 4: 228.0, 8: 228.5.
 #ifndef RTX_LEAF_BATCH
-#define RTX_LEAF_BATCH 8
+#define RTX_LEAF_BATCH 1
 #endif
 constexpr int kLeafBatch = RTX_LEAF_BATCH;
 #ifndef RTX_WALK_MIN_WAVES
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
       if (inner) { walk8_inner(sc, ray, 0.001f, c.t, w, st); ++n_nodes; }
       // leaves wait until a batch of lanes has one, or until no lane has an inner node left
       const bool leaf = state == 1 && walk8_at_leaf(w);
-      if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
+      if (kLeafBatch <= 1 || __popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
 #ifdef RTX_WALK_STATS
         { const unsigned long long ml = __ballot(leaf); if ((threadIdx.x & 63) == 0 && ml) { atomicAdd(&g_walk_stats[3], 1ull); atomicAdd(&g_walk_stats[4], (unsigned long long)__popcll(ml)); } }
 #endif
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<
       const bool inner = state == 1 && walk8_at_inner(w);
       if (inner) walk8_inner<false>(sc, sr, 0.001f, c.t, w, st);   // any hit ends the query: no nearest-first order
       const bool leaf = state == 1 && walk8_at_leaf(w);
-      if (__popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
+      if (kLeafBatch <= 1 || __popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
         if (leaf) walk8_leaf<true>(sc, sr, 0.001f, c, w, st);
       }
       if (state == 1 && w.node == kWalkDone) state = c.type >= 0 ? 2 : 3;   // (wf_shade has tested the planes and lights)
