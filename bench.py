@@ -201,11 +201,13 @@ def roofline(args, abi, jobs, stats, world):
     on the launch stream, rtx_stats.seconds_main_kernel).  The instruction count is a property of (kernel binary, workload):
     every lane's work items are fixed by its index, so it is taken from the committed rocprofv3 --pmc profile of this very
     workload - and only if that profile names the shared library that has just been timed (SHA-256), else it is null.
-    Queue pipeline (c5): the traversal kernel is bound by incoherent record fetches from HBM.  The kernel counts live the node
-    and leaf records it fetches; that figure x record bytes / its live time is the rate at which it consumes records
-    (`record_fetch_GBps`), of which the caches serve the top of the tree.  `achieved` is what HBM itself delivered: the
-    FETCH_SIZE + WRITE_SIZE bytes of the kernel's launches in the committed profile of this library build and workload / the
-    live time (null when no such profile exists), so that frac is a share of the HBM peak."""
+    Queue pipeline (c5): the closest-hit kernel fetches one 64-byte record per step of every ray, scattered over a tree far larger
+    than the caches.  It counts live the node and leaf records it fetches; achieved = that count x 64 bytes / its live time (HIP
+    events around every launch), against the 8 TB/s HBM peak.  traffic = what reached the L2's memory side in the committed
+    profile of this library build and workload: FETCH_SIZE as tallied + WRITE_SIZE (the counter tallies 64 bytes per request,
+    which is exact for scattered 64-byte records and half the truth for streaming reads: scripts/gather_calib.sh); the difference
+    to the record bytes is what the caches served.  The same profile's VALUBusy and active-lane share are reported beside it:
+    the kernel saturates vector-ALU issue as well."""
     first = [s for i, s in enumerate(stats) if i % len(jobs) == 0]   # scene 0 of every step
     n = len(first)
     seg = sum(s.segments for s in first) / n
@@ -253,11 +255,13 @@ def roofline(args, abi, jobs, stats, world):
             r.update({"record_fetch_GBps": alg / ext_s / 1e9, "record_bytes_per_launch_set": alg,
                       "node_records_per_ray": nodes / rays, "leaf_records_per_ray": prims / rays, "node_record_bytes": rec_b, "leaf_record_bytes": info.leaf_bytes,
                       "grays_per_s_closest_hit": rays / ext_s / 1e9})
+            r.update({"achieved": alg / ext_s / 1e9, "frac": alg / ext_s / 1e9 / HBM_PEAK_GBPS})
             if prof and prof.get("hbm_bytes_per_launch"):
                 hbm = prof["hbm_bytes_per_launch"]
-                r.update({"achieved": hbm / ext_s / 1e9, "frac": hbm / ext_s / 1e9 / HBM_PEAK_GBPS, "traffic": hbm, "share_of_record_bytes_served_by_caches": 1.0 - hbm / alg,
-                          "lanes_active": prof.get("lanes_active"), "l2_hit_rate": prof.get("l2_hit_rate"), "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"),
-                          "kernel_symbol": prof.get("kernel")})
+                r.update({"traffic": hbm, "traffic_GBps": hbm / ext_s / 1e9, "traffic_frac_of_peak": hbm / ext_s / 1e9 / HBM_PEAK_GBPS,
+                          "share_of_record_bytes_served_by_caches": 1.0 - hbm / alg, "traffic_rule": prof.get("hbm_bytes_rule"),
+                          "lanes_active": prof.get("lanes_active"), "valu_busy": prof.get("valu_busy"), "l2_hit_rate": prof.get("l2_hit_rate"),
+                          "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"), "kernel_symbol": prof.get("kernel")})
     return r
 
 

@@ -34,7 +34,8 @@ for cfg in (sys.argv[1:] or ["c2", "c3", "c5"]):
         "workload": [name, W, H, spp, depth, 1], "lib_sha256": lib, "kernel": k, "renders_profiled": renders,
         "launches_per_render": e["dispatches"] / renders,
         # sums over the kernel's launches of ONE render of the workload
-        "SQ_INSTS_VALU": c["SQ_INSTS_VALU"] / renders, "hbm_bytes_per_launch": d.get("hbm_bytes", 0.0) / renders or None,
+        "SQ_INSTS_VALU": c["SQ_INSTS_VALU"] / renders, "hbm_bytes_per_launch": d.get("hbm_bytes_scattered_64B" if cfg == "c5" else "hbm_bytes", 0.0) / renders or None,
+        "hbm_bytes_rule": "FETCH_SIZE as tallied (64-byte requests: scattered 64-byte records) + WRITE_SIZE" if cfg == "c5" else "2 x FETCH_SIZE (128-byte requests tallied at 64) + WRITE_SIZE",
         "lanes_active": d.get("lanes_active"), "valu_busy": d.get("valu_busy"), "valu_dual_issue_share": d.get("valu_dual_issue_share"), "l2_hit_rate": d.get("l2_hit_rate"), "kernel_ms_rocprof": e.get("ms_per_render"),
         "source": f"profiles/r02_prof_{cfg}.json (rocprofv3 --kernel-trace --stats and separate --pmc passes of: bench.py {s.get('bench_args')})",
     }

@@ -48,8 +48,14 @@ for k, e in K.items():
     if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU", 0) > 0:
         d["lanes_active"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        d["hbm_bytes"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0   # FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950
-        if e.get("total_ms"): d["hbm_GBps"] = d["hbm_bytes"] / (e["total_ms"] * 1e-3) / 1e9
+        # FETCH_SIZE = 64 bytes x read requests at the L2's memory side, whatever their size.  A streaming read makes 128-byte
+        # requests (double it); the tree walk's scattered 64-byte records make 64-byte requests (take it as it is): both measured
+        # with scripts/gather_calib.sh on tables of known size.
+        d["hbm_bytes"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        d["hbm_bytes_scattered_64B"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        if e.get("total_ms"):
+            d["hbm_GBps"] = d["hbm_bytes"] / (e["total_ms"] * 1e-3) / 1e9
+            d["hbm_GBps_scattered_64B"] = d["hbm_bytes_scattered_64B"] / (e["total_ms"] * 1e-3) / 1e9
     if "TCC_HIT_sum" in c and c["TCC_HIT_sum"] + c.get("TCC_MISS_sum", 0) > 0:
         d["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES", 0) > 0:
