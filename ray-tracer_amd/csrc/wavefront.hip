@@ -55,6 +55,12 @@ struct WfControl { uint32_t n_q[3]; uint32_t n_shadow[2]; uint32_t cursor_rays, 
 // One turn: wf_shade reads the ray queue A.q[q_in] of n_q[n_in] entries, fills A.q[q_out] / n_q[n_out] and clears n_q[n_zero];
 // its shadow rays are counted in n_shadow[sh] (it clears the other one).
 struct WfTurn { int q_in, q_out, n_in, n_out, n_zero, sh; };
+// Statistics of the streaming kernels.  Every workgroup adds its counts to the bank its index selects: atomics on ONE address
+// serialise at the L2 (a few nanoseconds each, four per workgroup and turn), atomics on different lines do not.  wf_stats_fold
+// adds the banks up at the end of a render.
+struct alignas(64) WfStatBank { unsigned long long segments, shadow, closest, samples, pad[4]; };
+constexpr int kStatBanks = 64;
+struct WfShared { WfControl ctl; WfStatBank bank[kStatBanks]; };
 
 // A persistent traversal wave runs its leaf step when at least this many lanes have a leaf record pending (or none has a node).
 // With one primitive per leaf record the step is short, and waiting for company does not pay: measured on the 10 M-triangle scene
@@ -94,7 +100,7 @@ RTX_DEV uint32_t wave_append(uint32_t* counter) {
 // Workgroup size of the two streaming kernels (wf_generate, wf_shade): as large as the hardware allows, since each
 // workgroup costs one atomic on the queue's shared counter and those serialise at the L2.
 constexpr int kStreamBlock = RTX_STREAM_BLOCK;
-struct BlockScratch { uint32_t cnt[kStreamBlock / 64]; uint32_t base; uint32_t sum[2]; };
+struct BlockScratch { uint32_t cnt[kStreamBlock / 64]; uint32_t cnt_b[kStreamBlock / 64]; uint32_t base, base_b; uint32_t sum[4]; };
 
 // Entry of the queue for each thread with `want` (0xffffffff for the others).
 RTX_DEV uint32_t block_append(BlockScratch& bs, uint32_t* counter, bool want) {
@@ -115,21 +121,51 @@ RTX_DEV uint32_t block_append(BlockScratch& bs, uint32_t* counter, bool want) {
   return want ? at : 0xffffffffu;
 }
 
-// counter_a += threads with pa, counter_b += threads with pb.
-RTX_DEV void block_count2(BlockScratch& bs, unsigned long long* counter_a, bool pa, unsigned long long* counter_b, bool pb) {
-  const unsigned long long ma = __ballot(pa), mb = __ballot(pb);
-  __syncthreads();
-  if (threadIdx.x == 0) { bs.sum[0] = 0u; bs.sum[1] = 0u; }
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
-    if (ma) atomicAdd(&bs.sum[0], (uint32_t)__popcll(ma));
-    if (mb) atomicAdd(&bs.sum[1], (uint32_t)__popcll(mb));
-  }
+// Two queues at once (one wait for both atomics): entries for the threads with want_a / want_b, 0xffffffff for the others.
+RTX_DEV void block_append2(BlockScratch& bs, uint32_t* counter_a, bool want_a, uint32_t& at_a, uint32_t* counter_b, bool want_b, uint32_t& at_b) {
+  const unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), waves = (int)(blockDim.x >> 6);
+  __syncthreads();   // a previous use of bs is over
+  if (lane == 0) { bs.cnt[wave] = (uint32_t)__popcll(ma); bs.cnt_b[wave] = (uint32_t)__popcll(mb); }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (bs.sum[0]) atomicAdd(counter_a, (unsigned long long)bs.sum[0]);
-    if (bs.sum[1]) atomicAdd(counter_b, (unsigned long long)bs.sum[1]);
+    uint32_t total = 0;
+    for (int k = 0; k < waves; ++k) total += bs.cnt[k];
+    bs.base = total ? atomicAdd(counter_a, total) : 0u;
+  } else if (threadIdx.x == 64) {
+    uint32_t total = 0;
+    for (int k = 0; k < waves; ++k) total += bs.cnt_b[k];
+    bs.base_b = total ? atomicAdd(counter_b, total) : 0u;
   }
+  __syncthreads();
+  uint32_t a = bs.base, b = bs.base_b;
+  for (int k = 0; k < wave; ++k) { a += bs.cnt[k]; b += bs.cnt_b[k]; }
+  a += (uint32_t)__popcll(ma & ((1ull << lane) - 1ull));
+  b += (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+  at_a = want_a ? a : 0xffffffffu;
+  at_b = want_b ? b : 0xffffffffu;
+}
+
+// The workgroup's counts of threads with each of four flags go to its statistics bank: segments, shadow, closest, samples.
+RTX_DEV void block_count4(BlockScratch& bs, WfStatBank* banks, bool segments, bool shadow, bool closest, bool samples) {
+  const unsigned long long m[4] = {__ballot(segments), __ballot(shadow), __ballot(closest), __ballot(samples)};
+  __syncthreads();
+  if (threadIdx.x < 4) bs.sum[threadIdx.x] = 0u;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (m[k]) atomicAdd(&bs.sum[k], (uint32_t)__popcll(m[k]));
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && bs.sum[threadIdx.x]) atomicAdd(&banks[blockIdx.x & (kStatBanks - 1)].segments + threadIdx.x, (unsigned long long)bs.sum[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void wf_stats_fold(const WfStatBank* __restrict__ banks, DCounters* counters) {
+  unsigned long long v[4] = {banks[threadIdx.x].segments, banks[threadIdx.x].shadow, banks[threadIdx.x].closest, banks[threadIdx.x].samples};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    for (int off = 32; off > 0; off >>= 1) v[k] += (unsigned long long)__shfl_xor((long long)v[k], off, 64);
+  if (threadIdx.x == 0) { counters->segments += v[0]; counters->shadow += v[1]; counters->closest += v[2]; counters->samples += v[3]; }
 }
 
 // (pixel, chunk) work item `item` of a render: where its pixel lies and which samples it covers.
@@ -147,7 +183,7 @@ RTX_DEV WorkItem work_item(const DRenderParams& P, uint32_t item) {
 
 // Slot i takes work item i (a render has at least as many items as slots) and starts its first sample; all slots go into ray
 // queue 0.
-__global__ __launch_bounds__(kStreamBlock) void wf_start(DCamera<float> cam, DRenderParams P, WfArrays A, WfControl* ctl, DCounters* counters) {
+__global__ __launch_bounds__(kStreamBlock) void wf_start(DCamera<float> cam, DRenderParams P, WfArrays A, WfControl* ctl, WfStatBank* banks) {
   const uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ BlockScratch bs;
   const bool live = sl < A.n_slots;
@@ -168,7 +204,7 @@ __global__ __launch_bounds__(kStreamBlock) void wf_start(DCamera<float> cam, DRe
   }
   const uint32_t at = block_append(bs, &ctl->n_q[0], live);
   if (live) A.q[0][at] = sl;
-  block_count2(bs, &counters->closest, live, &counters->samples, live);
+  block_count4(bs, banks, false, false, live, live);
 }
 
 // Sort key of a ray: the Morton code of its origin's cell in a 128^3 grid over the tree's bounding box (21 bits) above the
@@ -218,7 +254,10 @@ __device__ unsigned long long g_walk_stats[8];   // diagnostic build only
 
 // A wave takes its queue entries in chunks: one atomic on the shared cursor per kFeedChunk entries instead of one per refill.
 // All fields are the same in every lane.
-constexpr uint32_t kFeedChunk = 256;
+#ifndef RTX_FEED_CHUNK
+#define RTX_FEED_CHUNK 256
+#endif
+constexpr uint32_t kFeedChunk = RTX_FEED_CHUNK;
 struct WaveFeed { uint32_t next, end; bool dry; };
 
 // Entry of the queue of n for each lane with `want` (0xffffffff once the queue is used up); every lane of the wave calls it.
@@ -367,7 +406,7 @@ constexpr uint32_t kShadowToItem = 0x80000000u;
 
 template <int MODE, bool LDS_MATS, bool NMAP = false>
 __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCamera<float> cam, DRenderParams P, WfArrays A, WfControl* ctl, WfTurn turn,
-                                                   float* __restrict__ partial, DCounters* counters) {
+                                                   float* __restrict__ partial, WfStatBank* banks) {
   const DMaterial<float>* mats = sc.mats;
   if constexpr (LDS_MATS) mats = stage_materials(sc);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -440,17 +479,16 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
     A.bflags[slot] = ps.bounce_flags;
   }
   }
-  const uint32_t k = block_append(bs, &ctl->n_shadow[turn.sh], cast);
+  uint32_t k, at;
+  block_append2(bs, &ctl->n_shadow[turn.sh], cast, k, &ctl->n_q[turn.n_out], live, at);
   if (cast) {
     A.sh_slot[k] = sh_target;
     A.sh[0][k] = sh_ray.o.x; A.sh[1][k] = sh_ray.o.y; A.sh[2][k] = sh_ray.o.z;
     A.sh[3][k] = sh_ray.d.x; A.sh[4][k] = sh_ray.d.y; A.sh[5][k] = sh_ray.d.z; A.sh[6][k] = sh_tmax;
     A.sh_c[0][k] = sh_contrib.x; A.sh_c[1][k] = sh_contrib.y; A.sh_c[2][k] = sh_contrib.z;
   }
-  const uint32_t at = block_append(bs, &ctl->n_q[turn.n_out], live);
   if (live) A.q[turn.q_out][at] = slot;
-  block_count2(bs, &counters->segments, (did & STEP_SHADED) != 0, &counters->shadow, (did & STEP_SHADOW) != 0);
-  block_count2(bs, &counters->closest, live, &counters->samples, started);
+  block_count4(bs, banks, (did & STEP_SHADED) != 0, (did & STEP_SHADOW) != 0, live, started);
 }
 
 template <int MODE>
@@ -518,7 +556,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<
 }
 
 template <int MODE> void launch_turn_kernels(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, const WfArrays& A, WfControl* ctl,
-                                             float* partial, DCounters* counters, bool lds_mats, size_t mat_lds, int stack_levels, unsigned grid,
+                                             WfStatBank* banks, float* partial, DCounters* counters, bool lds_mats, size_t mat_lds, int stack_levels, unsigned grid,
                                              unsigned resident_blocks, const WfTurn* turn /* NULL: the start of a render */, hipStream_t stream, uint32_t& launches,
                                              WavefrontPool& pool) {
   const dim3 g((grid + (kStreamBlock / kBlock) - 1) / (kStreamBlock / kBlock)), bs(kStreamBlock), b(kBlock);   // `grid` counts kBlock-sized groups
@@ -534,15 +572,15 @@ template <int MODE> void launch_turn_kernels(const DScene<float>& sc, const DCam
   };
   int q_out = 0, n_out = 0;
   if (!turn) {
-    hipLaunchKernelGGL(wf_start, g, bs, 0, stream, cam, P, A, ctl, counters);
+    hipLaunchKernelGGL(wf_start, g, bs, 0, stream, cam, P, A, ctl, banks);
     ++launches;
   } else {
     q_out = turn->q_out; n_out = turn->n_out;
     if (MODE == MODE_TREE_UV && sc.n_nmaps > 0) {   // the instances that apply normal maps
-      if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true, MODE == MODE_TREE_UV>), g, bs, mat_lds, stream, sc, cam, P, A, ctl, *turn, partial, counters);
-      else hipLaunchKernelGGL((wf_shade<MODE, false, MODE == MODE_TREE_UV>), g, bs, 0, stream, sc, cam, P, A, ctl, *turn, partial, counters);
-    } else if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, cam, P, A, ctl, *turn, partial, counters);
-    else hipLaunchKernelGGL((wf_shade<MODE, false>), g, bs, 0, stream, sc, cam, P, A, ctl, *turn, partial, counters);
+      if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true, MODE == MODE_TREE_UV>), g, bs, mat_lds, stream, sc, cam, P, A, ctl, *turn, partial, banks);
+      else hipLaunchKernelGGL((wf_shade<MODE, false, MODE == MODE_TREE_UV>), g, bs, 0, stream, sc, cam, P, A, ctl, *turn, partial, banks);
+    } else if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, cam, P, A, ctl, *turn, partial, banks);
+    else hipLaunchKernelGGL((wf_shade<MODE, false>), g, bs, 0, stream, sc, cam, P, A, ctl, *turn, partial, banks);
     if (sorted) sort_queue(0, turn->sh, 1);
     hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, turn->sh, partial, stack_levels, sorted ? A.order_out : nullptr);
     launches += 2;
@@ -573,7 +611,7 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   if (items >= 0x7fffffffull) { err = "film too large for one launch"; return RTX_ERR_INVALID_ARGUMENT; }
   // Pool size: enough slots to keep every CU at full occupancy several times over.
   const uint32_t n_slots = (uint32_t)std::min<unsigned long long>(items, (unsigned long long)n_cus * 2048ull * (unsigned long long)RTX_POOL_MULT);
-  if (!pool.state.ensure((size_t)kWfArrays * n_slots * 4) || !pool.control.ensure(sizeof(WfControl)) ||
+  if (!pool.state.ensure((size_t)kWfArrays * n_slots * 4) || !pool.control.ensure(sizeof(WfShared)) ||
       !pool.queues.ensure((size_t)items * 3 * sizeof(float))) { err = "pool allocation"; return RTX_ERR_OUT_OF_MEMORY; }
   WfArrays A;
   {
@@ -606,7 +644,8 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
     if (rocprim::radix_sort_pairs(nullptr, bytes, A.key_in, A.key_out, A.order_in, A.order_out, (size_t)n_slots, 0u, kSortKeyBits, stream) != hipSuccess ||
         !pool.sort_tmp.ensure(bytes)) { err = "pool allocation (ray sort)"; return RTX_ERR_OUT_OF_MEMORY; }
   }
-  WfControl* ctl = (WfControl*)pool.control.ptr;
+  WfControl* ctl = &((WfShared*)pool.control.ptr)->ctl;
+  WfStatBank* banks = ((WfShared*)pool.control.ptr)->bank;
   float* partial = (float*)pool.queues.ptr;
   const size_t mat_bytes = (size_t)sc.n_mats * sizeof(DMaterial<float>);
   const bool lds_mats = mat_bytes <= kMaxLdsMaterialBytes;
@@ -617,11 +656,11 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   const unsigned resident = (unsigned)n_cus * (unsigned)per_cu;
 
   auto run = [&](const WfTurn* turn, unsigned grid) {
-    if (mode == MODE_FLAT) launch_turn_kernels<MODE_FLAT>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, turn, stream, launches, pool);
-    else if (mode == MODE_TREE) launch_turn_kernels<MODE_TREE>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, turn, stream, launches, pool);
-    else launch_turn_kernels<MODE_TREE_UV>(sc, cam, P, A, ctl, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, turn, stream, launches, pool);
+    if (mode == MODE_FLAT) launch_turn_kernels<MODE_FLAT>(sc, cam, P, A, ctl, banks, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, turn, stream, launches, pool);
+    else if (mode == MODE_TREE) launch_turn_kernels<MODE_TREE>(sc, cam, P, A, ctl, banks, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, turn, stream, launches, pool);
+    else launch_turn_kernels<MODE_TREE_UV>(sc, cam, P, A, ctl, banks, partial, counters, lds_mats, mat_lds, stack_levels, grid, resident, turn, stream, launches, pool);
   };
-  if (hipMemsetAsync(ctl, 0, sizeof(WfControl), stream) != hipSuccess) { err = "memset"; return RTX_ERR_HIP; }
+  if (hipMemsetAsync(pool.control.ptr, 0, sizeof(WfShared), stream) != hipSuccess) { err = "memset"; return RTX_ERR_HIP; }
   pool.events_used = 0;
   unsigned live_bound = n_slots;   // upper bound of the ray queue length (it only shrinks)
   unsigned grid = (live_bound + kBlock - 1) / kBlock;
@@ -639,8 +678,9 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
     }
     if (iter > 4000000u) { err = "iteration limit"; return RTX_ERR_HIP; }
   }
+  hipLaunchKernelGGL(wf_stats_fold, dim3(1), dim3(64), 0, stream, banks, counters);
   launch_film_reduce(partial, d_film, npix, P.n_chunks, P.spp, stream);
-  ++launches;
+  launches += 2;
 #ifdef RTX_WALK_STATS
   {
     unsigned long long h[8];
