@@ -36,7 +36,7 @@ struct WfArrays {
   float* bsdf_pdf;
   uint32_t *bflags, *xy, *pixel, *sample, *s_end, *cur, *next;
   float *hit_t, *hit_ua, *hit_ub;
-  int32_t *hit_id, *hit_uv;          // type << 24 | idx (or -1);  uv_kind << 24 | uv_idx
+  int32_t *hit_id, *hit_uv;          // type << kIdBits | idx (or -1);  uv_kind << kIdBits | uv_idx
   uint32_t* q[2];
   uint32_t* sh_slot;
   float* sh[7];                       // origin, direction, t_max
@@ -51,6 +51,11 @@ struct WfArrays {
 // Queue lengths and the cursors the persistent kernels hand their entries out from.  No kernel runs between wf_connect and the
 // wf_extend after it, so each has a cursor of its own; the counters rotate so that the one a turn fills was cleared a turn earlier
 // (by wf_shade, after every kernel that read it has finished).
+// A stored hit packs the primitive's type above its index within that type: scenes with 2^28 or more primitives of one type are
+// refused by wavefront_render.
+constexpr int kIdBits = 28;
+constexpr int kIdMask = (1 << kIdBits) - 1;
+
 struct WfControl { uint32_t n_q[3]; uint32_t n_shadow[2]; uint32_t cursor_rays, cursor_shadow; };
 // One turn: wf_shade reads the ray queue A.q[q_in] of n_q[n_in] entries, fills A.q[q_out] / n_q[n_out] and clears n_q[n_zero];
 // its shadow rays are counted in n_shadow[sh] (it clears the other one).
@@ -321,10 +326,10 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
         float t = 0.f, ua = 0.f, ub = 0.f;
         if constexpr (MODE == MODE_FLAT) {
           Hit<float> h;   // flat scenes: the candidate is cheap to redo in the shade kernel; keep t + id
-          if (flat_closest(sc, ray, 0.001f, 1e9f, h)) { id = (h.type << 24) | h.idx; t = h.t; }
+          if (flat_closest(sc, ray, 0.001f, 1e9f, h)) { id = (h.type << kIdBits) | h.idx; t = h.t; }
         } else {
           if (!tree) test_unbounded(sc, ray, 0.001f, c);   // (after a tree walk, wf_shade tests the planes and lights: every lane is busy there)
-          if (c.type >= 0) { id = (c.type << 24) | c.idx; t = c.t; ua = c.ua; ub = c.ub; uv = (c.uv_kind << 24) | (c.uv_idx & 0xffffff); }
+          if (c.type >= 0) { id = (c.type << kIdBits) | c.idx; t = c.t; ua = c.ua; ub = c.ub; uv = (c.uv_kind << kIdBits) | (c.uv_idx & kIdMask); }
         }
         A.hit_t[slot] = t; A.hit_id[slot] = id;
         if constexpr (MODE == MODE_TREE_UV) { A.hit_ua[slot] = ua; A.hit_ub[slot] = ub; A.hit_uv[slot] = uv; }
@@ -386,11 +391,11 @@ template <int MODE> RTX_DEV bool wf_load_hit(const DScene<float>& sc, const WfAr
   if (id < 0 && !tree) return false;
   Cand<float> c;
   cand_init(c, 1e9f);
-  if (id >= 0) { c.t = A.hit_t[slot]; c.type = id >> 24; c.idx = id & 0xffffff; }
+  if (id >= 0) { c.t = A.hit_t[slot]; c.type = id >> kIdBits; c.idx = id & kIdMask; }
   if constexpr (MODE == MODE_TREE_UV) {
     if (id >= 0) {
       const int uv = A.hit_uv[slot];
-      c.ua = A.hit_ua[slot]; c.ub = A.hit_ub[slot]; c.uv_kind = uv >> 24; c.uv_idx = uv & 0xffffff;
+      c.ua = A.hit_ua[slot]; c.ub = A.hit_ub[slot]; c.uv_kind = uv >> kIdBits; c.uv_idx = uv & kIdMask;
     }
   }
   if (tree) test_unbounded(sc, ray, 0.001f, c);
@@ -609,6 +614,8 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   const unsigned long long npix = (unsigned long long)P.rows * P.width;
   const unsigned long long items = npix * (unsigned long long)P.n_chunks;
   if (items >= 0x7fffffffull) { err = "film too large for one launch"; return RTX_ERR_INVALID_ARGUMENT; }
+  for (int count : {sc.n_spheres, sc.n_planes, sc.n_tris, sc.n_boxes, sc.n_quads, sc.n_disks})
+    if (count > kIdMask) { err = "the queue pipeline indexes at most 2^28 primitives of one type"; return RTX_ERR_UNSUPPORTED; }
   // Pool size: enough slots to keep every CU at full occupancy several times over.
   const uint32_t n_slots = (uint32_t)std::min<unsigned long long>(items, (unsigned long long)n_cus * 2048ull * (unsigned long long)RTX_POOL_MULT);
   if (!pool.state.ensure((size_t)kWfArrays * n_slots * 4) || !pool.control.ensure(sizeof(WfShared)) ||
