@@ -201,13 +201,15 @@ def roofline(args, abi, jobs, stats, world):
     on the launch stream, rtx_stats.seconds_main_kernel).  The instruction count is a property of (kernel binary, workload):
     every lane's work items are fixed by its index, so it is taken from the committed rocprofv3 --pmc profile of this very
     workload - and only if that profile names the shared library that has just been timed (SHA-256), else it is null.
-    Queue pipeline (c5): the closest-hit kernel fetches one 64-byte record per step of every ray, scattered over a tree far larger
-    than the caches.  It counts live the node and leaf records it fetches; achieved = that count x 64 bytes / its live time (HIP
-    events around every launch), against the 8 TB/s HBM peak.  traffic = what reached the L2's memory side in the committed
-    profile of this library build and workload: FETCH_SIZE as tallied + WRITE_SIZE (the counter tallies 64 bytes per request,
-    which is exact for scattered 64-byte records and half the truth for streaming reads: scripts/gather_calib.sh); the difference
-    to the record bytes is what the caches served.  The same profile's VALUBusy and active-lane share are reported beside it:
-    the kernel saturates vector-ALU issue as well."""
+    Queue pipeline (c5): the closest-hit kernel walks every queued ray through the eight-wide tree, one 64-byte record per step,
+    scattered over a tree far larger than the caches.  Its profile shows vector-ALU issue saturated (VALUBusy above 100 %) at the
+    same instruction rate the fused kernel reaches, with the memory side at well under half its peak: the bound is the same
+    VALU ceiling, achieved = VALU wave-instructions of the kernel's launches (committed profile of this library build and
+    workload) / the kernel's live time (HIP events around every launch).  The memory side is reported beside it under "hbm":
+    achieved = records fetched (counted live by the kernel) x 64 bytes / the same time, against the 8 TB/s peak; traffic = what
+    reached the L2's memory side in the profile, FETCH_SIZE as tallied + WRITE_SIZE (the counter tallies 64 bytes per request,
+    exact for scattered 64-byte records, half the truth for streaming reads: scripts/gather_calib.sh); the difference to the
+    record bytes is what the caches served."""
     first = [s for i, s in enumerate(stats) if i % len(jobs) == 0]   # scene 0 of every step
     n = len(first)
     seg = sum(s.segments for s in first) / n
@@ -248,20 +250,28 @@ def roofline(args, abi, jobs, stats, world):
         rays = sum(s.rays_closest for s in first) / n
         info = j0["pt"].bvh_info()
         rec_b = info.wide_bytes / max(1, info.wide_nodes)
-        r.update({"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "kernel": "wf_extend (closest-hit traversal of the ray queue)",
-                  "kernel_ms": ext_s * 1e3, "frame_ms": kern_s * 1e3, "achieved": None, "frac": None, "traffic": None})
+        peak = N_SIMDS * CLOCK_HZ / VALU_CYCLES_PER_INST / 1e9
+        r.update({"bound": "valu", "unit": "Gwave-inst/s", "peak": peak, "kernel": "wf_extend (closest-hit walk of the ray queue through the eight-wide tree)",
+                  "peak_definition": "two wave64 instructions per SIMD per 4 cycles (dual issue) x 1024 SIMDs x 2.4 GHz",
+                  "single_issue_rate": peak / 2, "measured_stream_rates": VALU_STREAM_RATES,
+                  "kernel_ms": ext_s * 1e3, "frame_ms": kern_s * 1e3, "achieved": None, "frac": None, "traffic": None, "lanes_active": None, "valu_busy": None})
         if ext_s > 0 and nodes > 0:
             alg = nodes * rec_b + prims * info.leaf_bytes
-            r.update({"record_fetch_GBps": alg / ext_s / 1e9, "record_bytes_per_launch_set": alg,
-                      "node_records_per_ray": nodes / rays, "leaf_records_per_ray": prims / rays, "node_record_bytes": rec_b, "leaf_record_bytes": info.leaf_bytes,
-                      "grays_per_s_closest_hit": rays / ext_s / 1e9})
-            r.update({"achieved": alg / ext_s / 1e9, "frac": alg / ext_s / 1e9 / HBM_PEAK_GBPS})
-            if prof and prof.get("hbm_bytes_per_launch"):
-                hbm = prof["hbm_bytes_per_launch"]
-                r.update({"traffic": hbm, "traffic_GBps": hbm / ext_s / 1e9, "traffic_frac_of_peak": hbm / ext_s / 1e9 / HBM_PEAK_GBPS,
-                          "share_of_record_bytes_served_by_caches": 1.0 - hbm / alg, "traffic_rule": prof.get("hbm_bytes_rule"),
-                          "lanes_active": prof.get("lanes_active"), "valu_busy": prof.get("valu_busy"), "l2_hit_rate": prof.get("l2_hit_rate"),
+            hbm = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": alg / ext_s / 1e9, "frac": alg / ext_s / 1e9 / HBM_PEAK_GBPS,
+                   "achieved_definition": "node and leaf records fetched (counted live by the kernel) x 64 bytes / the kernel's live time",
+                   "record_bytes_per_launch_set": alg, "traffic": None}
+            r.update({"node_records_per_ray": nodes / rays, "leaf_records_per_ray": prims / rays, "node_record_bytes": rec_b, "leaf_record_bytes": info.leaf_bytes,
+                      "grays_per_s_closest_hit": rays / ext_s / 1e9, "hbm": hbm})
+            if prof:
+                ach = prof["SQ_INSTS_VALU"] / ext_s / 1e9
+                r.update({"achieved": ach, "frac": ach / peak, "lanes_active": prof.get("lanes_active"), "valu_busy": prof.get("valu_busy"),
+                          "valu_wave_insts_per_ray": prof["SQ_INSTS_VALU"] / rays, "l2_hit_rate": prof.get("l2_hit_rate"),
                           "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"), "kernel_symbol": prof.get("kernel")})
+                if prof.get("hbm_bytes_per_launch"):
+                    t = prof["hbm_bytes_per_launch"]
+                    hbm.update({"traffic": t, "traffic_GBps": t / ext_s / 1e9, "traffic_frac_of_peak": t / ext_s / 1e9 / HBM_PEAK_GBPS,
+                                "share_of_record_bytes_served_by_caches": 1.0 - t / alg, "traffic_rule": prof.get("hbm_bytes_rule")})
+                    r["traffic"] = t
     return r
 
 
