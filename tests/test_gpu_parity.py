@@ -574,6 +574,31 @@ def test_error_paths(pkg, load_scene):
         pkg.renderer.HipPathTracer(1 << 20)
 
 
+@pytest.mark.parametrize("W,H,spp,shards", [(3, 2, 1, 1), (5, 4, 17, 1), (16, 9, 33, 1), (7, 5, 16, 2), (64, 33, 3, 3)])
+@pytest.mark.parametrize("name", ["cornell_box_quad", "soup"])
+def test_wavefront_pipeline_small_and_ragged_work(name, W, H, spp, shards, pkg, tracer, load_scene):
+    """Films smaller than one workgroup of the queue pipeline, sample counts that are not a multiple of the chunk a slot sums
+    (the last chunk of a pixel is shorter; a slot's last path of a work item sends its light sample to that item's sum), row
+    shards: the queue pipeline still counts every sample once and agrees with the fused kernel."""
+    sd = soup_scene(pkg, load_scene) if name == "soup" else load_scene(name)
+    pt = tracer(sd)
+    pt.set_camera(sd.camera(W, H))
+    for shard in range(shards):
+        rows = len(range(shard, H, shards))
+        base = dict(width=W, height=H, samples_per_pixel=spp, max_depth=min(sd.max_depth, 12), seed=5, shard_index=shard, shard_count=shards)
+        pt.set_settings(sd.settings(pipeline=pkg.abi.PIPELINE_FUSED, **base))
+        a = pt.render().astype(np.float64)
+        sa = pt.last_stats
+        pt.set_settings(sd.settings(pipeline=pkg.abi.PIPELINE_WAVEFRONT, **base))
+        b = pt.render().astype(np.float64)
+        sb = pt.last_stats
+        assert a.shape == b.shape == (rows, W, 3)
+        assert sb.pipeline_used == pkg.abi.PIPELINE_WAVEFRONT and sb.samples == sa.samples == rows * W * spp
+        assert abs(int(sb.segments) - int(sa.segments)) <= max(2, 0.01 * sa.segments) and abs(int(sb.rays_shadow) - int(sa.rays_shadow)) <= max(2, 0.01 * sa.rays_shadow)
+        bad = (np.abs(a - b) > 1e-3 * (1.0 + np.abs(a))).any(axis=2)
+        assert bad.sum() <= max(1, 0.01 * bad.size), (int(bad.sum()), float(np.abs(a - b).max()))
+
+
 @pytest.mark.parametrize("force_mode", [None, "0", "1"])
 @pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "environment_demo", "kitchen_sink", "textured", "soup", "normal_mapped", "sphere_field"])
 def test_wavefront_pipeline_equals_fused(name, force_mode, pkg, tracer, load_scene, monkeypatch):
