@@ -77,9 +77,11 @@ template <class F> void parallel_for(size_t n, F&& f) {
   for (std::thread& t : th) t.join();
 }
 
-struct BuildPrim { double lo[3], hi[3]; int32_t index, type; };
-
-inline double cen(const BuildPrim& p, int ax) { return (p.lo[ax] + p.hi[ax]) * 0.5; }  // ref: bvh.hpp:89-95
+// A primitive's box, numbered as the reference's primitive list (spheres, then triangles, then boxes), and what the median
+// splits move around: its centroid (ref: bvh.hpp:89-95) and that number.  32-byte keys instead of the reference's 56-byte
+// BVHPrimitive: std::nth_element makes the same comparisons and therefore the same moves, on fewer bytes.
+struct BuildBox { double lo[3], hi[3]; };
+struct BuildKey { double c[3]; int32_t number, pad; };
 
 size_t subtree_nodes(size_t count) {
   if (count <= 2) return 1;
@@ -88,42 +90,49 @@ size_t subtree_nodes(size_t count) {
 }
 
 struct Builder {
-  Staging<BuildPrim>& prims;
+  const Staging<BuildBox>& boxes;
+  Staging<BuildKey>& keys;
   Staging<DNodeRef>& nodes;
 
   void build(size_t me, size_t start, size_t end, int depth) {
     DNodeRef& nd = nodes[me];
-    double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};   // ref: bvh.hpp:26-27
-    double clo[3] = {1e30, 1e30, 1e30}, chi[3] = {-1e30, -1e30, -1e30};
-    // min / max are exact and order-independent, so a large range is reduced in slices
-    auto bounds = [&](size_t b, size_t e, double* lo, double* hi, double* clo, double* chi) {
-      for (size_t i = b; i < e; ++i)
+    const size_t count = end - start;
+    if (count <= 2) {
+      double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};   // ref: bvh.hpp:26-27
+      for (size_t i = start; i < end; ++i) {
+        const BuildBox& p = boxes[(size_t)keys[i].number];
         for (int a = 0; a < 3; ++a) {
           // AABB::expand(other): expand(min) then expand(max), each an fmin + an fmax (bvh.hpp:69-84)
-          lo[a] = std::fmin(std::fmin(lo[a], prims[i].lo[a]), prims[i].hi[a]);
-          hi[a] = std::fmax(std::fmax(hi[a], prims[i].lo[a]), prims[i].hi[a]);
-          double c = cen(prims[i], a); clo[a] = std::fmin(clo[a], c); chi[a] = std::fmax(chi[a], c);
+          lo[a] = std::fmin(std::fmin(lo[a], p.lo[a]), p.hi[a]);
+          hi[a] = std::fmax(std::fmax(hi[a], p.lo[a]), p.hi[a]);
         }
+      }
+      for (int a = 0; a < 3; ++a) { nd.lo[a] = lo[a]; nd.hi[a] = hi[a]; }
+      nd.left = -1; nd.right = -1; nd.first = (int32_t)start; nd.count = (int32_t)count;
+      return;
+    }
+    double clo[3] = {1e30, 1e30, 1e30}, chi[3] = {-1e30, -1e30, -1e30};
+    // min / max are exact and order-independent, so a large range is reduced in slices
+    auto bounds = [&](size_t b, size_t e, double* clo, double* chi) {
+      for (size_t i = b; i < e; ++i)
+        for (int a = 0; a < 3; ++a) { const double c = keys[i].c[a]; clo[a] = std::fmin(clo[a], c); chi[a] = std::fmax(chi[a], c); }
     };
-    if (end - start > ((size_t)1 << 20)) {
+    if (count > ((size_t)1 << 20)) {
       std::mutex mu;
-      parallel_for(end - start, [&](size_t b, size_t e) {
-        double l[3] = {1e30, 1e30, 1e30}, h[3] = {-1e30, -1e30, -1e30}, cl[3] = {1e30, 1e30, 1e30}, ch[3] = {-1e30, -1e30, -1e30};
-        bounds(start + b, start + e, l, h, cl, ch);
+      parallel_for(count, [&](size_t b, size_t e) {
+        double cl[3] = {1e30, 1e30, 1e30}, ch[3] = {-1e30, -1e30, -1e30};
+        bounds(start + b, start + e, cl, ch);
         std::lock_guard<std::mutex> g(mu);
-        for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], l[a]); hi[a] = std::fmax(hi[a], h[a]); clo[a] = std::fmin(clo[a], cl[a]); chi[a] = std::fmax(chi[a], ch[a]); }
+        for (int a = 0; a < 3; ++a) { clo[a] = std::fmin(clo[a], cl[a]); chi[a] = std::fmax(chi[a], ch[a]); }
       });
     } else {
-      bounds(start, end, lo, hi, clo, chi);
+      bounds(start, end, clo, chi);
     }
-    for (int a = 0; a < 3; ++a) { nd.lo[a] = lo[a]; nd.hi[a] = hi[a]; }
-    size_t count = end - start;
-    if (count <= 2) { nd.left = -1; nd.right = -1; nd.first = (int32_t)start; nd.count = (int32_t)count; return; }
     double dx = chi[0] - clo[0], dy = chi[1] - clo[1], dz = chi[2] - clo[2];
     int axis = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);   // ref: bvh.hpp:100-107
     size_t mid = start + count / 2;
-    std::nth_element(prims.begin() + start, prims.begin() + mid, prims.begin() + end,
-                     [axis](const BuildPrim& a, const BuildPrim& b) { return cen(a, axis) < cen(b, axis); });
+    std::nth_element(keys.begin() + start, keys.begin() + mid, keys.begin() + end,
+                     [axis](const BuildKey& a, const BuildKey& b) { return a.c[axis] < b.c[axis]; });
     size_t left = me + 1, right = me + 1 + subtree_nodes(mid - start);
     nd.left = (int32_t)left; nd.right = (int32_t)right; nd.first = 0; nd.count = 0;
     if (count > 32768 && depth < 6) {
@@ -134,6 +143,11 @@ struct Builder {
       build(left, start, mid, depth + 1);
       build(right, mid, end, depth + 1);
     }
+    // The reference expands a node's box by every primitive of its range in turn (bvh.hpp:176-180); fmin / fmax are exact,
+    // commutative and associative, so the union of the two children's boxes is that box.
+    const DNodeRef& l = nodes[left];
+    const DNodeRef& r = nodes[right];
+    for (int a = 0; a < 3; ++a) { nd.lo[a] = std::fmin(l.lo[a], r.lo[a]); nd.hi[a] = std::fmax(l.hi[a], r.hi[a]); }
   }
 };
 
@@ -176,10 +190,11 @@ void build_env_tables(const rtx_environment& e, std::vector<double>& marginal, s
   else for (int y = 1; y <= h; ++y) marginal[y] = (double)y / h;
 }
 
-template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& pool, const rtx_scene_desc& d, const HostBvh& bvh,
-                                   const std::vector<int32_t>& emissive, const DImage* d_images, const DPrimRef* d_prims,
-                                   const float* d_env_texels, const std::vector<double>& marginal, const std::vector<double>& conditional,
-                                   double env_total, bool& ok) {
+// Everything of the device scene that does not depend on the reference-order tree.
+template <class R> void fill_geometry(DScene<R>& sc, std::vector<DeviceBuffer>& pool, const rtx_scene_desc& d,
+                                      const std::vector<int32_t>& emissive, const DImage* d_images,
+                                      const float* d_env_texels, const std::vector<double>& marginal, const std::vector<double>& conditional,
+                                      double env_total, bool& ok) {
   memset(&sc, 0, sizeof sc);
   std::vector<DSphere<R>> sph(d.n_spheres);
   for (size_t i = 0; i < d.n_spheres; ++i) { cp3(sph[i].c, d.spheres[i].center); sph[i].radius = (R)d.spheres[i].radius; sph[i].mat = d.spheres[i].material_id; sph[i].pad = 0; }
@@ -224,6 +239,30 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
     cp3(mats[i].c1, m.tex_color1); cp3(mats[i].c2, m.tex_color2); mats[i].scale = (R)m.tex_scale;
     mats[i].nmap_image = m.has_normal_map ? m.normal_image : -1; mats[i].pad = 0; mats[i].nmap_strength = (R)m.normal_strength;
   }
+  sc.spheres = push(pool, sph, ok); sc.planes = push(pool, pls, ok); sc.boxes = push(pool, boxes, ok);
+  if constexpr (!std::is_same<R, double>::value) sc.tris = push(pool, tris, ok);
+  sc.points = push(pool, pts, ok); sc.quads = push(pool, quads, ok); sc.disks = push(pool, disks, ok); sc.mats = push(pool, mats, ok);
+  sc.emissive = push(pool, emissive, ok);
+  sc.images = d_images;
+  sc.n_spheres = (int)d.n_spheres; sc.n_planes = (int)d.n_planes; sc.n_tris = (int)d.n_triangles; sc.n_boxes = (int)d.n_boxes;
+  sc.n_points = (int)d.n_point_lights; sc.n_quads = (int)d.n_quad_lights; sc.n_disks = (int)d.n_disk_lights; sc.n_mats = (int)d.n_materials;
+  sc.n_images = (int)d.n_images; sc.n_emissive = (int)emissive.size();
+  sc.n_nmaps = 0;
+  for (size_t i = 0; i < d.n_materials; ++i) sc.n_nmaps += d.materials[i].has_normal_map ? 1 : 0;
+  if (d_env_texels) {
+    std::vector<R> mg(marginal.begin(), marginal.end()), cd(conditional.begin(), conditional.end());
+    sc.env.texel = d_env_texels;
+    sc.env.marginal = push(pool, mg, ok); sc.env.conditional = push(pool, cd, ok);
+    sc.env.w = d.environment->width; sc.env.h = d.environment->height;
+    sc.env.intensity = (R)d.environment->intensity; sc.env.rotation = (R)d.environment->rotation;
+    sc.env.valid = 1; sc.env.importance = env_total > 0.0 ? 1 : 0;   // ref: engine/texture.hpp:478-480, :692-694
+  }
+}
+
+}  // namespace
+
+// What the device scene takes from the reference-order tree.
+template <class R> void fill_tree(DScene<R>& sc, std::vector<DeviceBuffer>& pool, const rtx_scene_desc& d, const HostBvh& bvh, const DPrimRef* d_prims, bool& ok) {
   // Double precision walks the reference tree's topology (left child = i + 1), so that closest hits keep the reference's bits
   // whatever the visiting order.  Single precision walks the eight-wide tree built on the GPU (HostScene::upload).
   Staging<DNode2<R>> nodes;
@@ -250,42 +289,23 @@ template <class R> void fill_scene(DScene<R>& sc, std::vector<DeviceBuffer>& poo
     for (size_t i = 0; i < d.n_disk_lights; ++i) rec((float)d.disk_lights[i].normal[0], (float)d.disk_lights[i].normal[1], (float)d.disk_lights[i].normal[2], 0.f, -1000 - (int)i, PRIM_DISK, (int)i);
     sc.flat = push(pool, recs, ok);
   }
-  sc.spheres = push(pool, sph, ok); sc.planes = push(pool, pls, ok); sc.boxes = push(pool, boxes, ok);
-  if constexpr (!std::is_same<R, double>::value) sc.tris = push(pool, tris, ok);
-  sc.points = push(pool, pts, ok); sc.quads = push(pool, quads, ok); sc.disks = push(pool, disks, ok); sc.mats = push(pool, mats, ok);
   if constexpr (std::is_same<R, double>::value) sc.nodes = push(pool, nodes, ok);
-  sc.emissive = push(pool, emissive, ok);
-  sc.images = d_images; sc.prims = d_prims;
-  sc.n_spheres = (int)d.n_spheres; sc.n_planes = (int)d.n_planes; sc.n_tris = (int)d.n_triangles; sc.n_boxes = (int)d.n_boxes;
-  sc.n_points = (int)d.n_point_lights; sc.n_quads = (int)d.n_quad_lights; sc.n_disks = (int)d.n_disk_lights; sc.n_mats = (int)d.n_materials;
-  sc.n_images = (int)d.n_images; sc.n_emissive = (int)emissive.size();
-  sc.n_nmaps = 0;
-  for (size_t i = 0; i < d.n_materials; ++i) sc.n_nmaps += d.materials[i].has_normal_map ? 1 : 0;
+  sc.prims = d_prims;
   sc.n_nodes = (int)bvh.nodes.size(); sc.n_prims = (int)bvh.prims.size();
-  if (d_env_texels) {
-    std::vector<R> mg(marginal.begin(), marginal.end()), cd(conditional.begin(), conditional.end());
-    sc.env.texel = d_env_texels;
-    sc.env.marginal = push(pool, mg, ok); sc.env.conditional = push(pool, cd, ok);
-    sc.env.w = d.environment->width; sc.env.h = d.environment->height;
-    sc.env.intensity = (R)d.environment->intensity; sc.env.rotation = (R)d.environment->rotation;
-    sc.env.valid = 1; sc.env.importance = env_total > 0.0 ? 1 : 0;   // ref: engine/texture.hpp:478-480, :692-694
-  }
 }
-
-}  // namespace
 
 void HostBvh::build(const rtx_scene_desc& d) {
   auto t0 = std::chrono::steady_clock::now();
   nodes.clear(); prims.clear();
   const size_t ns = d.n_spheres, nt = d.n_triangles, nb = d.n_boxes;
-  Staging<BuildPrim> bp(ns + nt + nb);
+  Staging<BuildBox> bp(ns + nt + nb);
   for (size_t i = 0; i < ns; ++i) {   // ref: engine/scene.hpp:500-510
-    BuildPrim& p = bp[i]; p.type = PRIM_SPHERE; p.index = (int32_t)i;
+    BuildBox& p = bp[i];
     for (int a = 0; a < 3; ++a) { p.lo[a] = d.spheres[i].center[a] - d.spheres[i].radius; p.hi[a] = d.spheres[i].center[a] + d.spheres[i].radius; }
   }
   parallel_for(nt, [&](size_t b, size_t e) {   // ref: engine/scene.hpp:513-522
     for (size_t i = b; i < e; ++i) {
-      BuildPrim& p = bp[ns + i]; p.type = PRIM_TRIANGLE; p.index = (int32_t)i;
+      BuildBox& p = bp[ns + i];
       const rtx_triangle& t = d.triangles[i];
       for (int a = 0; a < 3; ++a) {
         p.lo[a] = std::fmin(std::fmin(std::fmin(1e30, t.v0[a]), t.v1[a]), t.v2[a]);
@@ -294,15 +314,35 @@ void HostBvh::build(const rtx_scene_desc& d) {
     }
   });
   for (size_t i = 0; i < nb; ++i) {      // ref: engine/scene.hpp:525-533
-    BuildPrim& p = bp[ns + nt + i]; p.type = PRIM_BOX; p.index = (int32_t)i;
+    BuildBox& p = bp[ns + nt + i];
     for (int a = 0; a < 3; ++a) { p.lo[a] = d.boxes[i].box_min[a]; p.hi[a] = d.boxes[i].box_max[a]; }
   }
+  const bool timing = getenv("RTX_TIMING") != nullptr;   // diagnostics: phase times on stderr
+  auto lap = [&](const char* what) {
+    if (timing) fprintf(stderr, "[rtx upload]   reference tree: %-28s %7.1f ms since its start\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
+  };
+  lap("primitive boxes");
   if (!bp.empty()) {
+    Staging<BuildKey> keys(bp.size());
+    parallel_for(bp.size(), [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        for (int a = 0; a < 3; ++a) keys[i].c[a] = (bp[i].lo[a] + bp[i].hi[a]) * 0.5;   // ref: bvh.hpp:89-95
+        keys[i].number = (int32_t)i; keys[i].pad = 0;
+      }
+    });
+    lap("centroid keys");
     nodes.resize(subtree_nodes(bp.size()));
-    Builder b{bp, nodes};
+    Builder b{bp, keys, nodes};
     b.build(0, 0, bp.size(), 0);
+    lap("median splits");
     prims.resize(bp.size());
-    parallel_for(bp.size(), [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) { prims[i].type = bp[i].type; prims[i].index = bp[i].index; } });
+    parallel_for(bp.size(), [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        const size_t k = (size_t)keys[i].number;
+        prims[i].type = k < ns ? PRIM_SPHERE : k < ns + nt ? PRIM_TRIANGLE : PRIM_BOX;
+        prims[i].index = (int32_t)(k < ns ? k : k < ns + nt ? k - ns : k - ns - nt);
+      }
+    });
   }
   seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -316,7 +356,7 @@ void HostScene::release() {
   n_nodes = n_prims = 0;
 }
 
-int prepare_scene(const rtx_scene_desc& d, ScenePrep& out, std::string& err) {
+int validate_scene(const rtx_scene_desc& d, std::string& err) {
   const size_t lim = 0x7fffffff;
   if (d.n_spheres > lim || d.n_planes > lim || d.n_triangles > lim || d.n_boxes > lim || d.n_materials > lim ||
       d.n_spheres + d.n_triangles + d.n_boxes > lim / 2) { err = "too many primitives"; return RTX_ERR_INVALID_ARGUMENT; }
@@ -340,16 +380,25 @@ int prepare_scene(const rtx_scene_desc& d, ScenePrep& out, std::string& err) {
     if (m.has_normal_map && (m.normal_image < 0 || (size_t)m.normal_image >= d.n_images)) { err = "material normal map index out of range"; return RTX_ERR_INVALID_ARGUMENT; }
   }
   for (size_t i = 0; i < d.n_images; ++i) if (!d.images[i].rgb || d.images[i].width <= 0 || d.images[i].height <= 0) { err = "bad image"; return RTX_ERR_INVALID_ARGUMENT; }
+  return RTX_OK;
+}
 
+// The emissive spheres, ascending (ref: engine/scene.hpp:222-230).
+static std::vector<int32_t> emissive_spheres(const rtx_scene_desc& d) {
+  std::vector<int32_t> out;
+  for (size_t i = 0; i < d.n_spheres; ++i) {
+    const rtx_material& m = d.materials[d.spheres[i].material_id];
+    if (m.emission[0] > 0.0 || m.emission[1] > 0.0 || m.emission[2] > 0.0) out.push_back((int32_t)i);
+  }
+  return out;
+}
+
+void build_scene_prep(const rtx_scene_desc& d, ScenePrep& out) {
   const bool timing = getenv("RTX_TIMING") != nullptr;   // diagnostics: phase times on stderr
   const auto t0 = std::chrono::steady_clock::now();
   out.bvh.build(d);
   const HostBvh& bvh = out.bvh;
-  out.emissive.clear();   // ref: engine/scene.hpp:222-230
-  for (size_t i = 0; i < d.n_spheres; ++i) {
-    const rtx_material& m = d.materials[d.spheres[i].material_id];
-    if (m.emission[0] > 0.0 || m.emission[1] > 0.0 || m.emission[2] > 0.0) out.emissive.push_back((int32_t)i);
-  }
+  out.emissive = emissive_spheres(d);
   out.rank.clear(); out.dead.clear();
   if (bvh.prims.size() > (size_t)kLinearMaxPrims) {
     // What the GPU-built tree takes from the reference-order tree: every primitive's position in the reference's leaf order (ties
@@ -370,25 +419,33 @@ int prepare_scene(const rtx_scene_desc& d, ScenePrep& out, std::string& err) {
       }
     });
   }
-  if (timing) fprintf(stderr, "[rtx upload] %-28s %8.1f ms\n", "validate, reference tree", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  if (timing) fprintf(stderr, "[rtx upload] %-28s %8.1f ms\n", "reference tree, ranks", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
+
+int prepare_scene(const rtx_scene_desc& d, ScenePrep& out, std::string& err) {
+  const int rc = validate_scene(d, err);
+  if (rc != RTX_OK) return rc;
+  build_scene_prep(d, out);
   return RTX_OK;
 }
 
-int HostScene::upload(const rtx_scene_desc& d, const ScenePrep& prep, std::string& err) {
-  release();
-  const bool timing = getenv("RTX_TIMING") != nullptr;   // diagnostics: phase times of the upload on stderr
-  auto t_prev = std::chrono::steady_clock::now();
-  auto lap = [&](const char* what) {
-    if (!timing) return;
+namespace {
+struct UploadLap {
+  bool on = getenv("RTX_TIMING") != nullptr;   // diagnostics: phase times of the upload on stderr
+  std::chrono::steady_clock::time_point t_prev = std::chrono::steady_clock::now();
+  void operator()(const char* what) {
+    if (!on) return;
     auto t = std::chrono::steady_clock::now();
     fprintf(stderr, "[rtx upload] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
     t_prev = t;
-  };
-  const HostBvh& bvh = prep.bvh;
-  build_seconds = bvh.seconds;
-  n_nodes = (int)bvh.nodes.size(); n_prims = (int)bvh.prims.size();
+  }
+};
+}  // namespace
 
-  const std::vector<int32_t>& emissive = prep.emissive;
+int HostScene::upload_geometry(const rtx_scene_desc& d, std::string& err) {
+  release();
+  UploadLap lap;
+  const std::vector<int32_t> emissive = emissive_spheres(d);
   bool ok = true;
   std::vector<DImage> imgs(d.n_images);
   for (size_t i = 0; i < d.n_images; ++i) {
@@ -397,9 +454,6 @@ int HostScene::upload(const rtx_scene_desc& d, const ScenePrep& prep, std::strin
     imgs[i].rgb = (const uint8_t*)pool.back().ptr; imgs[i].w = d.images[i].width; imgs[i].h = d.images[i].height;
   }
   const DImage* d_images = push(pool, imgs, ok);
-  const DPrimRef* d_prims = push(pool, bvh.prims, ok);
-  const DNodeRef* d_nodes_ref = push(pool, bvh.nodes, ok);
-
   const float* d_env = nullptr;
   std::vector<double> marginal, conditional;
   double env_total = 0.0;
@@ -410,12 +464,29 @@ int HostScene::upload(const rtx_scene_desc& d, const ScenePrep& prep, std::strin
     if (!pool.back().upload(e->rgb, (size_t)e->width * e->height * 3 * sizeof(float))) ok = false;
     d_env = (const float*)pool.back().ptr;
   }
-  lap("images, reference tree, env");
-  fill_scene(dev_d, pool, d, bvh, emissive, d_images, d_prims, d_env, marginal, conditional, env_total, ok);
+  lap("images, env");
+  fill_geometry(dev_d, pool, d, emissive, d_images, d_env, marginal, conditional, env_total, ok);
   lap("double-precision scene");
-  fill_scene(dev_f, pool, d, bvh, emissive, d_images, d_prims, d_env, marginal, conditional, env_total, ok);
+  fill_geometry(dev_f, pool, d, emissive, d_images, d_env, marginal, conditional, env_total, ok);
   lap("single-precision scene");
+  h_spheres.assign(d.spheres, d.spheres + d.n_spheres);
+  h_materials.assign(d.materials, d.materials + d.n_materials);
+  if (!ok) { release(); err = "device allocation or copy failed"; return RTX_ERR_OUT_OF_MEMORY; }
+  return RTX_OK;
+}
+
+int HostScene::upload_tree(const rtx_scene_desc& d, const ScenePrep& prep, std::string& err) {
+  UploadLap lap;
+  const HostBvh& bvh = prep.bvh;
+  build_seconds = bvh.seconds;
+  n_nodes = (int)bvh.nodes.size(); n_prims = (int)bvh.prims.size();
+  bool ok = true;
+  const DPrimRef* d_prims = push(pool, bvh.prims, ok);
+  const DNodeRef* d_nodes_ref = push(pool, bvh.nodes, ok);
+  fill_tree(dev_d, pool, d, bvh, d_prims, ok);
+  fill_tree(dev_f, pool, d, bvh, d_prims, ok);
   dev_ref.nodes = d_nodes_ref; dev_ref.prims = d_prims; dev_ref.n_nodes = n_nodes; dev_ref.n_prims = n_prims;
+  lap("reference tree");
   if (ok && bvh.prims.size() > (size_t)kLinearMaxPrims) {
     dev_f.rank = push(pool, prep.rank, ok);
     const uint8_t* d_dead = prep.dead.empty() ? nullptr : push(pool, prep.dead, ok);
@@ -438,8 +509,6 @@ int HostScene::upload(const rtx_scene_desc& d, const ScenePrep& prep, std::strin
     }
     lap("eight-wide tree (GPU)");
   }
-  h_spheres.assign(d.spheres, d.spheres + d.n_spheres);
-  h_materials.assign(d.materials, d.materials + d.n_materials);
   if (!ok) { release(); err = "device allocation or copy failed"; return RTX_ERR_OUT_OF_MEMORY; }
   return RTX_OK;
 }

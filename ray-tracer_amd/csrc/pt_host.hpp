@@ -63,6 +63,10 @@ struct ScenePrep {
   std::vector<int32_t> emissive;
 };
 // Validates the description and fills `out`; RTX_OK or an error code with `err` set.
+// prepare_scene = validate_scene, then build_scene_prep.  build_scene_prep makes no device call: a caller may run it on a host
+// thread of its own while the scene's tables are on their way to the device (HostScene::upload_geometry).
+int validate_scene(const rtx_scene_desc& d, std::string& err);
+void build_scene_prep(const rtx_scene_desc& d, ScenePrep& out);
 int prepare_scene(const rtx_scene_desc& d, ScenePrep& out, std::string& err);
 
 struct HostScene {
@@ -75,8 +79,15 @@ struct HostScene {
   std::vector<DeviceBuffer> pool;   // owns every other device allocation of the scene
   std::vector<rtx_sphere> h_spheres;   // host copies the PathPhoton photon pass is planned from
   std::vector<rtx_material> h_materials;
-  // Copies the scene to the current device and builds the eight-wide tree there; `prep` = prepare_scene(d).
-  int upload(const rtx_scene_desc& d, const ScenePrep& prep, std::string& err);
+  // Copies the scene to the current device and builds the eight-wide tree there, in two steps: the tables that do not depend on
+  // the reference-order tree (a validated scene), then the tree, what derives from it, and the eight-wide tree; `prep` =
+  // prepare_scene(d).
+  int upload_geometry(const rtx_scene_desc& d, std::string& err);
+  int upload_tree(const rtx_scene_desc& d, const ScenePrep& prep, std::string& err);
+  int upload(const rtx_scene_desc& d, const ScenePrep& prep, std::string& err) {
+    const int rc = upload_geometry(d, err);
+    return rc != RTX_OK ? rc : upload_tree(d, prep, err);
+  }
   int upload(const rtx_scene_desc& d, std::string& err) {
     ScenePrep prep;
     const int rc = prepare_scene(d, prep, err);

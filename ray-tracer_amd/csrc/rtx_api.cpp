@@ -368,26 +368,47 @@ static int upload_impl(rtx_ctx* c, const rtx_scene_desc* d) {
   ++c->scene_generation;
   for (rtx_ctx* p : c->peers) ++p->scene_generation;
   std::string err;
-  ScenePrep prep;   // the reference-order tree and what derives from it: built once, whatever the number of devices
-  int rc = prepare_scene(*d, prep, err);
+  int rc = validate_scene(*d, err);
   if (rc != RTX_OK) return fail(rc, "upload_scene: %s", err.c_str());
+  // The reference-order tree and what derives from it: built once, whatever the number of devices, on a host thread of its own
+  // (it makes no device call) while the scene's tables travel to the devices.
+  ScenePrep prep;
+  int prep_rc = RTX_OK;
+  std::string prep_err;
+  std::thread prep_thread([&] {
+    try { build_scene_prep(*d, prep);
+    } catch (const std::bad_alloc&) { prep_rc = RTX_ERR_OUT_OF_MEMORY; prep_err = "host allocation failed";
+    } catch (const std::exception& e) { prep_rc = RTX_ERR_HIP; prep_err = e.what(); }
+  });
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } join_on_every_path{prep_thread};
   // every device takes its copy over its own host link and builds its eight-wide tree itself (the build is deterministic,
   // so the trees are identical): one host thread per device
   std::vector<rtx_ctx*> all{c};
   all.insert(all.end(), c->peers.begin(), c->peers.end());
   std::vector<int> rcs(all.size(), RTX_OK);
   std::vector<std::string> errs(all.size());
-  auto one = [&](size_t k) {
+  auto guarded_step = [&](size_t k, auto&& step) {
+    if (rcs[k] != RTX_OK) return;
     try {
       if (hipSetDevice(all[k]->device) != hipSuccess) { rcs[k] = RTX_ERR_HIP; errs[k] = "hipSetDevice failed"; return; }
-      rcs[k] = all[k]->scene.upload(*d, prep, errs[k]);
+      rcs[k] = step();
     } catch (const std::bad_alloc&) { rcs[k] = RTX_ERR_OUT_OF_MEMORY; errs[k] = "host allocation failed";
     } catch (const std::exception& e) { rcs[k] = RTX_ERR_HIP; errs[k] = e.what(); }
   };
-  std::vector<std::thread> th;
-  for (size_t k = 1; k < all.size(); ++k) th.emplace_back(one, k);
-  one(0);
-  for (std::thread& t : th) t.join();
+  auto per_device = [&](auto&& body) {
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < all.size(); ++k) th.emplace_back(body, k);
+    body((size_t)0);
+    for (std::thread& t : th) t.join();
+  };
+  per_device([&](size_t k) { guarded_step(k, [&] { return all[k]->scene.upload_geometry(*d, errs[k]); }); });
+  prep_thread.join();
+  if (prep_rc != RTX_OK) {
+    for (rtx_ctx* x : all) x->scene.release();
+    (void)hipSetDevice(c->device);
+    return fail(prep_rc, "upload_scene: %s", prep_err.c_str());
+  }
+  per_device([&](size_t k) { guarded_step(k, [&] { return all[k]->scene.upload_tree(*d, prep, errs[k]); }); });
   (void)hipSetDevice(c->device);
   for (size_t k = 0; k < all.size(); ++k)
     if (rcs[k] != RTX_OK) return fail(rcs[k], "upload_scene (device %d): %s", all[k]->device, errs[k].c_str());
