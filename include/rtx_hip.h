@@ -270,6 +270,16 @@ typedef struct rtx_bvh_info {
 } rtx_bvh_info;
 int rtx_get_bvh_info(rtx_ctx* ctx, rtx_bvh_info* out);
 
+/* Validation: the reference-order tree as this library built it and as rtx_trace_closest and the double-precision mode walk it -
+ * the node array and the primitive list BVH::build leaves behind (engine/bvh.hpp:148-218; a node is BVHNode, bvh.hpp:124-130:
+ * its box, `left` / `right` child or `first` / `count` of a leaf; a primitive is its type, RTX_PRIM_*, and its index within that
+ * type).  Copied back from the device.  `nodes` holds rtx_bvh_info::ref_nodes entries, prim_types / prim_indices ref_prims each. */
+typedef struct rtx_bvh_node {
+  double lo[3], hi[3];
+  int32_t left, right, first, count;
+} rtx_bvh_node;
+int rtx_get_reference_bvh(rtx_ctx* ctx, rtx_bvh_node* nodes, size_t n_nodes, int32_t* prim_types, int32_t* prim_indices, size_t n_prims);
+
 const char* rtx_last_error(void);
 
 #ifdef __cplusplus

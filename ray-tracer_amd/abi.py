@@ -132,6 +132,7 @@ EXPORTS = {
     "rtx_trace_closest_fast": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_int, C.POINTER(Hit)]),
     "rtx_shard_rows": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "rtx_get_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(BvhInfo)]),
+    "rtx_get_reference_bvh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtx_last_error": (C.c_char_p, []),
 }
 

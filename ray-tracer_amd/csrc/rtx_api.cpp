@@ -448,6 +448,22 @@ int rtx_get_bvh_info(rtx_ctx* c, rtx_bvh_info* out) {
   return RTX_OK;
 }
 
+int rtx_get_reference_bvh(rtx_ctx* c, rtx_bvh_node* nodes, size_t n_nodes, int32_t* prim_types, int32_t* prim_indices, size_t n_prims) {
+  return guarded([&]() -> int {
+    if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "no scene uploaded");
+    if (n_nodes != (size_t)c->scene.n_nodes || n_prims != (size_t)c->scene.n_prims)
+      return fail(RTX_ERR_INVALID_ARGUMENT, "the tree has %d nodes and %d primitives (rtx_get_bvh_info), the buffers hold %zu and %zu", c->scene.n_nodes, c->scene.n_prims, n_nodes, n_prims);
+    if ((n_nodes && !nodes) || (n_prims && (!prim_types || !prim_indices))) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL buffer");
+    static_assert(sizeof(rtx_bvh_node) == sizeof(DNodeRef) && offsetof(rtx_bvh_node, left) == offsetof(DNodeRef, left), "layout");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n_nodes) HIP_TRY(hipMemcpy(nodes, c->scene.dev_ref.nodes, n_nodes * sizeof(DNodeRef), hipMemcpyDeviceToHost));
+    std::vector<DPrimRef> prims(n_prims);
+    if (n_prims) HIP_TRY(hipMemcpy(prims.data(), c->scene.dev_ref.prims, n_prims * sizeof(DPrimRef), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n_prims; ++i) { prim_types[i] = prims[i].type; prim_indices[i] = prims[i].index; }
+    return RTX_OK;
+  });
+}
 
 // `no_alloc`: the render may not allocate (rtx_render_device_noalloc): its chunk sums and counters go to the device's scratch
 // array, and whatever would need another buffer is refused.

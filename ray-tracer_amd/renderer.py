@@ -139,6 +139,18 @@ class HipPathTracer:
         return info
 
 
+    def reference_bvh(self):
+        """The reference-order tree as the library built it (rtx_get_reference_bvh): (boxes [n, 6] float64 = lo, hi;
+        nodes [n, 4] int32 = left, right, first, count; prims [m, 2] int32 = type, index)."""
+        info = self.bvh_info()
+        n, m = int(info.ref_nodes), int(info.ref_prims)
+        node_dtype = np.dtype([("box", np.float64, 6), ("ints", np.int32, 4)])
+        nodes = np.zeros(n, dtype=node_dtype)
+        types, indices = np.zeros(m, dtype=np.int32), np.zeros(m, dtype=np.int32)
+        abi.check(self._lib, self._lib.rtx_get_reference_bvh(self._ctx, nodes.ctypes.data, n, types.ctypes.data, indices.ctypes.data, m), "rtx_get_reference_bvh")
+        return np.ascontiguousarray(nodes["box"]), np.ascontiguousarray(nodes["ints"]), np.stack([types, indices], axis=1)
+
+
 def test_hip(device_id: int = 0) -> bool:
     """Counterpart of raytracer::cuda::test_cuda() (engine/cuda/cuda_api.hpp:17)."""
     lib = abi.load_library()

@@ -93,6 +93,30 @@ def test_fast_path_closest_hit_agreement(name, pkg, tracer, load_scene):
     assert int((~agree).sum()) <= F32_ID_MISMATCH_RAYS.get(name, 0), int((~agree).sum())
 
 
+@pytest.mark.parametrize("case", ["kitchen_sink", "soup", "stress_300k_with_duplicates", "stress_1500k"])
+def test_reference_order_tree_equals_the_oracles(case, pkg, oracle, tracer, load_scene):
+    """The reference-order tree the library builds (32-byte keys, node boxes bottom-up, large subtrees on host threads of their
+    own) is, node for node and primitive for primitive, the tree BVH::build makes (engine/bvh.hpp:148-218), which the oracle
+    restates with the reference's own 56-byte primitives and one std::nth_element per node: boxes bit for bit, child / leaf
+    fields, and the order std::nth_element leaves the primitives in - also where centroids are equal."""
+    if case in ("kitchen_sink", "soup"):
+        sd = soup_scene(pkg, load_scene) if case == "soup" else load_scene(case)
+    else:
+        n = 300_000 if case.startswith("stress_300k") else 1_500_000
+        sd = pkg.synthetic.stress_scene(n, seed=11)
+        if case.endswith("duplicates"):
+            tri = sd.triangle_array
+            tri[1::7] = tri[0:-1:7][: len(tri[1::7])]          # every seventh triangle twice: equal centroids on every axis
+            tri["v0"][2::11, 0] = 1.25                          # and runs of equal x
+            sd.triangle_array = tri
+    pt = tracer(sd)
+    boxes, ints, prims = pt.reference_bvh()
+    oboxes, oints, oprims = oracle.OracleScene(sd).bvh()
+    assert prims.shape == oprims.shape and np.array_equal(prims, oprims)
+    assert np.array_equal(ints, oints)
+    assert np.array_equal(bits(boxes), bits(oboxes))
+
+
 @pytest.mark.parametrize("n_tris,n_spheres,n_boxes", [(13, 0, 0), (0, 13, 0), (5, 5, 4), (27, 3, 2), (64, 0, 1), (65, 7, 0), (500, 13, 11), (5000, 50, 50), (40000, 0, 0)])
 def test_mixed_primitive_trees_of_many_sizes(n_tris, n_spheres, n_boxes, pkg, tracer, load_scene):
     """Trees of one node, of odd and even numbers of inner children, and of several levels, over triangles, spheres and boxes
