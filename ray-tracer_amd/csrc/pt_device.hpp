@@ -328,12 +328,12 @@ struct LaneStack {
 // primitives are 30 levels).  The single-precision kernels walk the eight-wide tree with walk_stack_slots(levels) words; a scene
 // whose tree is deeper than kMaxWalkLevels is refused at upload.
 
-template <class R> RTX_DEV R slab_entry(const DNode2<R>& nd, const Ray<R>& r, V3<R> inv, R t_min, R t_max, bool& ok) {
-  R t0 = (nd.lo[0] - r.o.x) * inv.x, t1 = (nd.hi[0] - r.o.x) * inv.x;
+template <class R> RTX_DEV R slab_entry(const DNodeRef& nd, const Ray<R>& r, V3<R> inv, R t_min, R t_max, bool& ok) {
+  R t0 = (R(nd.lo[0]) - r.o.x) * inv.x, t1 = (R(nd.hi[0]) - r.o.x) * inv.x;
   R lo = min_(t0, t1), hi = max_(t0, t1);
-  t0 = (nd.lo[1] - r.o.y) * inv.y; t1 = (nd.hi[1] - r.o.y) * inv.y;
+  t0 = (R(nd.lo[1]) - r.o.y) * inv.y; t1 = (R(nd.hi[1]) - r.o.y) * inv.y;
   lo = max_(lo, min_(t0, t1)); hi = min_(hi, max_(t0, t1));
-  t0 = (nd.lo[2] - r.o.z) * inv.z; t1 = (nd.hi[2] - r.o.z) * inv.z;
+  t0 = (R(nd.lo[2]) - r.o.z) * inv.z; t1 = (R(nd.hi[2]) - r.o.z) * inv.z;
   lo = max_(lo, min_(t0, t1)); hi = min_(hi, max_(t0, t1));
   lo = max_(lo, t_min); hi = min_(hi, t_max);
   ok = lo < hi;   // strict: a box that is flat along an axis is never entered, as in the reference (bvh.hpp:43)
@@ -354,30 +354,30 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
   int sp = 0;
   int node = 0;
   for (;;) {
-    const DNode2<R> nd = sc.nodes[node];
+    const DNodeRef nd = sc.nodes[node];
     bool ok;
     slab_entry(nd, r, inv, t_min, c.t, ok);
     bool descend = false;
     if (ok) {
       if (nd.count > 0) {
         for (int i = 0; i < nd.count; ++i) {
-          DPrimRef p = sc.prims[nd.a + i];
+          DPrimRef p = sc.prims[nd.first + i];
           test_bounded(sc, p.type, p.index, r, t_min, c);
         }
         if (ANY && c.type >= 0) return true;
       } else {
         // visit the nearer child first; the other goes on the stack
         bool ok_l, ok_r;
-        const DNode2<R> l = sc.nodes[node + 1];
-        const DNode2<R> rr = sc.nodes[nd.a];
+        const DNodeRef l = sc.nodes[node + 1];
+        const DNodeRef rr = sc.nodes[nd.right];
         R el = slab_entry(l, r, inv, t_min, c.t, ok_l);
         R er = slab_entry(rr, r, inv, t_min, c.t, ok_r);
         if (ok_l && ok_r) {
-          int near = el <= er ? node + 1 : nd.a, far = el <= er ? nd.a : node + 1;
+          int near = el <= er ? node + 1 : nd.right, far = el <= er ? nd.right : node + 1;
           st.push(sp, far);
           node = near; descend = true;
         } else if (ok_l) { node = node + 1; descend = true; }
-        else if (ok_r) { node = nd.a; descend = true; }
+        else if (ok_r) { node = nd.right; descend = true; }
       }
     }
     if (!descend) {

@@ -262,21 +262,8 @@ template <class R> void fill_geometry(DScene<R>& sc, std::vector<DeviceBuffer>& 
 }  // namespace
 
 // What the device scene takes from the reference-order tree.
-template <class R> void fill_tree(DScene<R>& sc, std::vector<DeviceBuffer>& pool, const rtx_scene_desc& d, const HostBvh& bvh, const DPrimRef* d_prims, bool& ok) {
-  // Double precision walks the reference tree's topology (left child = i + 1), so that closest hits keep the reference's bits
-  // whatever the visiting order.  Single precision walks the eight-wide tree built on the GPU (HostScene::upload).
-  Staging<DNode2<R>> nodes;
-  if constexpr (std::is_same<R, double>::value) {
-    nodes.resize(bvh.nodes.size());
-    parallel_for(bvh.nodes.size(), [&](size_t b, size_t e) {
-      for (size_t i = b; i < e; ++i) {
-        const DNodeRef& n = bvh.nodes[i];
-        for (int a = 0; a < 3; ++a) { nodes[i].lo[a] = n.lo[a]; nodes[i].hi[a] = n.hi[a]; }
-        if (n.count > 0) { nodes[i].a = n.first; nodes[i].count = n.count; }
-        else { nodes[i].a = n.right; nodes[i].count = 0; }
-      }
-    });
-  }
+template <class R> void fill_tree(DScene<R>& sc, std::vector<DeviceBuffer>& pool, const rtx_scene_desc& d, const HostBvh& bvh, const DNodeRef* d_nodes, const DPrimRef* d_prims,
+                                  bool& ok) {
   if (std::is_same<R, float>::value && d.n_triangles == 0 && d.n_boxes == 0 && d.n_spheres <= (size_t)kFlatMaxSpheres) {
     std::vector<DFlatRec> recs;
     auto rec = [&](float a, float b, float c, float w, int mat, int type, int idx) { recs.push_back(DFlatRec{a, b, c, w, mat, type, idx, 0}); };
@@ -289,7 +276,9 @@ template <class R> void fill_tree(DScene<R>& sc, std::vector<DeviceBuffer>& pool
     for (size_t i = 0; i < d.n_disk_lights; ++i) rec((float)d.disk_lights[i].normal[0], (float)d.disk_lights[i].normal[1], (float)d.disk_lights[i].normal[2], 0.f, -1000 - (int)i, PRIM_DISK, (int)i);
     sc.flat = push(pool, recs, ok);
   }
-  if constexpr (std::is_same<R, double>::value) sc.nodes = push(pool, nodes, ok);
+  // Double precision walks the reference-order tree itself (left child = i + 1), so that closest hits keep the reference's bits
+  // whatever the visiting order.  Single precision walks the eight-wide tree built on the GPU (HostScene::upload_tree).
+  sc.nodes = std::is_same<R, double>::value ? d_nodes : nullptr;
   sc.prims = d_prims;
   sc.n_nodes = (int)bvh.nodes.size(); sc.n_prims = (int)bvh.prims.size();
 }
@@ -483,8 +472,8 @@ int HostScene::upload_tree(const rtx_scene_desc& d, const ScenePrep& prep, std::
   bool ok = true;
   const DPrimRef* d_prims = push(pool, bvh.prims, ok);
   const DNodeRef* d_nodes_ref = push(pool, bvh.nodes, ok);
-  fill_tree(dev_d, pool, d, bvh, d_prims, ok);
-  fill_tree(dev_f, pool, d, bvh, d_prims, ok);
+  fill_tree(dev_d, pool, d, bvh, d_nodes_ref, d_prims, ok);
+  fill_tree(dev_f, pool, d, bvh, d_nodes_ref, d_prims, ok);
   dev_ref.nodes = d_nodes_ref; dev_ref.prims = d_prims; dev_ref.n_nodes = n_nodes; dev_ref.n_prims = n_prims;
   lap("reference tree");
   if (ok && bvh.prims.size() > (size_t)kLinearMaxPrims) {

@@ -29,10 +29,6 @@ struct DImage { const uint8_t* rgb; int32_t w, h; };
 struct DNodeRef { double lo[3], hi[3]; int32_t left, right, first, count; };
 struct DPrimRef { int32_t type, index; };
 
-// Production BVH node (32 bytes in float): the same binary topology in preorder, so the
-// left child of node i is i+1.  count > 0: leaf over prims[a .. a+count); else a = right child.
-template <class R> struct DNode2 { R lo[3], hi[3]; int32_t a, count; };
-
 // Single-precision traversal layout: an eight-wide tree built on the GPU (bvh_build.hip) from the Morton order of the
 // primitives' centroids.  Its topology is its own (closest hits do not depend on it: boxes are conservative, and a tie in t
 // is resolved by the primitives' positions in the REFERENCE's leaf order, DScene::rank); only the reference-order tree above
@@ -94,7 +90,7 @@ template <class R> struct DScene {
   const DSphere<R>* spheres; const DPlane<R>* planes; const DTri<R>* tris; const DBox<R>* boxes;
   const DPoint<R>* points; const DQuad<R>* quads; const DDisk<R>* disks; const DMaterial<R>* mats;
   const DImage* images; const int32_t* emissive;   // indices of emissive spheres, ascending
-  const DNode2<R>* nodes; const DPrimRef* prims;    // production BVH + primitive order (reference leaf order)
+  const DNodeRef* nodes; const DPrimRef* prims;     // double precision: the reference-order tree, walked nearest child first (left child of node i = i + 1); the reference's primitive order
   const DNode8* nodes8;                                // single-precision traversal layout: 64-byte units, node records and leaf records (NULL in the double scene and for scenes tested linearly)
   const int32_t* rank;                                 // position of every bounded primitive (numbered as in DLeaf::ref) in the reference's leaf order
   const DFlatRec* flat;                                // flat scenes only (single precision)
