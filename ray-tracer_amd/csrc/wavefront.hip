@@ -4,7 +4,8 @@
 // (pixel, chunk) work item and camera ray; after that one turn advances every live path by one
 // vertex with three kernels:
 //
-//   wf_extend           every queued slot's ray is traced to its closest hit
+//   wf_extend           every queued slot's ray is traced to its closest hit (scenes that walk a tree:
+//                       to its closest bounded primitive; wf_shade tests the planes and lights)
 //   wf_shade            the vertex is shaded (emission, MIS, light sample, scatter, roulette);
 //                       light samples that need a visibility test are compacted into the
 //                       shadow-ray queue; a slot whose path ended adds it to its chunk sum and
@@ -14,8 +15,9 @@
 //                       to the chunk sum of their slot
 //
 // Queues are compacted with ballot + prefix popcount and ONE atomic per workgroup.
-// The traversal kernels carry only a ray and a candidate, so they run at 2-4x the occupancy
-// of the fused kernel; that is what pays for the queue traffic on scenes that walk a tree.
+// The traversal kernels are persistent: a lane carries only a ray and a candidate and takes its
+// next ray from the queue when its walk ends, so a wave is not held back by its longest walk; that
+// is what pays for the queue traffic on scenes that walk a tree.
 // Per-slot arithmetic and sample order equal the fused kernel's, so films agree to rounding.
 #include <cstring>   // rocPRIM's headers use memset without including it
 
@@ -75,7 +77,7 @@ struct WfShared { WfControl ctl; WfStatBank bank[kStatBanks]; };
 #endif
 constexpr int kLeafBatch = RTX_LEAF_BATCH;
 #ifndef RTX_WALK_MIN_WAVES
-#define RTX_WALK_MIN_WAVES 1   // waves per SIMD the traversal kernels are compiled for (caps their registers): at 72 VGPRs they run 7; 8 (64 VGPRs, spills) measured 17 % slower
+#define RTX_WALK_MIN_WAVES 1   // waves per SIMD the traversal kernels are compiled for (caps their registers): left alone they take 73 VGPRs and run 6; capped at 72 (7 waves) or 64 (8) they are no faster (240 and 243 ms against 238 for the closest-hit walk of the 10 M-triangle frame)
 #endif
 
 
@@ -84,26 +86,13 @@ constexpr int kLeafBatch = RTX_LEAF_BATCH;
 #endif
 constexpr int kWfArrays = 6 + 3 + 3 + 3 + 1 + 7 + 3 + 2 + 2 + 1 + 7 + 3 + 4;   // 4-byte arrays of n_slots entries
 
-// Append to a queue from (possibly divergent) code: the active lanes of the wave take
-// consecutive entries with one atomic.
-RTX_DEV uint32_t wave_append(uint32_t* counter) {
-  const unsigned long long mask = __ballot(1);
-  const int lane = (int)(threadIdx.x & 63);
-  const int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-  base = (uint32_t)__shfl((int)base, leader, 64);
-  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-}
-
-// Workgroup-level forms for kernels whose every thread reaches the call (they synchronise the
-// workgroup): ONE atomic per workgroup.  A single hot counter takes a few nanoseconds per
-// atomic at the L2, which at one atomic per wave was most of these kernels' run time.
+// Queue appends of the streaming kernels (wf_start, wf_shade): every thread of the workgroup reaches the call (they synchronise
+// the workgroup), ONE returning atomic per workgroup and queue.  Returning atomics on one address serialise at about 11 ns each
+// (scripts/atomic_rate.hip), which at one atomic per wave was most of these kernels' run time; the workgroups are as large as the
+// hardware allows for the same reason (measured on the 10 M-triangle frame: 1024 threads 410 ms, 512: 490, 256: 613).
 #ifndef RTX_STREAM_BLOCK
 #define RTX_STREAM_BLOCK 1024
 #endif
-// Workgroup size of the two streaming kernels (wf_generate, wf_shade): as large as the hardware allows, since each
-// workgroup costs one atomic on the queue's shared counter and those serialise at the L2.
 constexpr int kStreamBlock = RTX_STREAM_BLOCK;
 struct BlockScratch { uint32_t cnt[kStreamBlock / 64]; uint32_t cnt_b[kStreamBlock / 64]; uint32_t base, base_b; uint32_t sum[4]; };
 
