@@ -490,7 +490,7 @@ int HostScene::upload_tree(const rtx_scene_desc& d, const ScenePrep& prep, std::
         return RTX_ERR_UNSUPPORTED;
       }
       dev_f.nodes8 = (const DNode8*)wide.nodes.ptr;
-      dev_f.n_nodes8 = wide.n_nodes; dev_f.n_leaves3 = wide.n_leaves; dev_f.walk_levels = wide.levels;
+      dev_f.n_nodes8 = wide.n_nodes; dev_f.n_leaves8 = wide.n_leaves; dev_f.walk_levels = wide.levels;
       for (int a = 0; a < 3; ++a) {
         dev_f.bb_lo[a] = wide.lo[a]; dev_f.bb_scale[a] = wide.hi[a] > wide.lo[a] ? 128.0f / (wide.hi[a] - wide.lo[a]) : 0.f;
         dev_f.wt_anchor[a] = wide.anchor[a]; dev_f.wt_step[a] = wide.step[a];

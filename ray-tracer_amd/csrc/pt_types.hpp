@@ -97,7 +97,7 @@ template <class R> struct DScene {
   float bb_lo[3], bb_scale[3];                         // the eight-wide tree's root box as a 128^3 grid: cell = (p - bb_lo) * bb_scale (ray sorting)
   float wt_anchor[3], wt_step[3];                      // the grid the node origins of the eight-wide tree lie on (DNode8::org)
   int32_t n_spheres, n_planes, n_tris, n_boxes, n_points, n_quads, n_disks, n_mats, n_images, n_emissive;
-  int32_t n_nodes, n_prims, n_nodes8, n_leaves3, walk_levels;
+  int32_t n_nodes, n_prims, n_nodes8, n_leaves8, walk_levels;
   int32_t n_nmaps;                                     // materials with a normal map (picks the kernel instances that apply them)
   DEnv<R> env;
 };
