@@ -58,7 +58,13 @@ struct WfArrays {
 constexpr int kIdBits = 28;
 constexpr int kIdMask = (1 << kIdBits) - 1;
 
-struct WfControl { uint32_t n_q[3]; uint32_t n_shadow[2]; uint32_t cursor_rays, cursor_shadow; };
+// Every counter has a 128-byte line of its own: a queue length that one kernel's workgroups read must not share a line with a
+// counter the same kernel's atomics hammer (with all seven in one line, wf_shade ran at one workgroup per 100 ns whatever the
+// workgroup's size).
+struct alignas(128) WfCounter { uint32_t v; uint32_t pad[31]; };
+struct WfControl {
+  WfCounter n_q_[3], n_shadow_[2], cursor_rays_, cursor_shadow_;
+};
 // One turn: wf_shade reads the ray queue A.q[q_in] of n_q[n_in] entries, fills A.q[q_out] / n_q[n_out] and clears n_q[n_zero];
 // its shadow rays are counted in n_shadow[sh] (it clears the other one).
 struct WfTurn { int q_in, q_out, n_in, n_out, n_zero, sh; };
@@ -88,8 +94,9 @@ constexpr int kWfArrays = 6 + 3 + 3 + 3 + 1 + 7 + 3 + 2 + 2 + 1 + 7 + 3 + 4;   /
 
 // Queue appends of the streaming kernels (wf_start, wf_shade): every thread of the workgroup reaches the call (they synchronise
 // the workgroup), ONE returning atomic per workgroup and queue.  Returning atomics on one address serialise at about 11 ns each
-// (scripts/atomic_rate.hip), which at one atomic per wave was most of these kernels' run time; the workgroups are as large as the
-// hardware allows for the same reason (measured on the 10 M-triangle frame: 1024 threads 410 ms, 512: 490, 256: 613).
+// (scripts/atomic_rate.hip), which at one atomic per wave was most of these kernels' run time.  With every counter on a line of
+// its own (WfControl) the workgroup size no longer matters (10 M-triangle frame: 1024 threads 398 ms, 512: 395, 256: 398; with
+// all counters in one line: 410 / 490 / 613); it stays at the largest.
 #ifndef RTX_STREAM_BLOCK
 #define RTX_STREAM_BLOCK 1024
 #endif
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(kStreamBlock) void wf_start(DCamera<float> cam, DRe
     A.bsdf_pdf[sl] = 0.f;
     A.bflags[sl] = F_ALIVE;
   }
-  const uint32_t at = block_append(bs, &ctl->n_q[0], live);
+  const uint32_t at = block_append(bs, &ctl->n_q_[0].v, live);
   if (live) A.q[0][at] = sl;
   block_count4(bs, banks, false, false, live, live);
 }
@@ -224,7 +231,7 @@ constexpr unsigned kSortKeyBits = 24;
 __global__ __launch_bounds__(256) void wf_sort_keys(DScene<float> sc, WfArrays A, const WfControl* __restrict__ ctl, int q /* ray queue array */, int nq /* its counter, or the shadow counter */, int shadow, uint32_t bound) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= bound) return;
-  const uint32_t n = shadow ? ctl->n_shadow[nq] : ctl->n_q[nq];
+  const uint32_t n = shadow ? ctl->n_shadow_[nq].v : ctl->n_q_[nq].v;
   uint32_t key = 0xffffffffu, entry = 0u;
   if (i < n) {
     if (shadow) {
@@ -287,7 +294,7 @@ RTX_DEV uint32_t feed_take(WaveFeed& f, uint32_t* cursor, bool want, uint32_t n)
 template <int MODE>
 __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int nq /* the queue's counter */, int stack_levels, DCounters* counters,
                                                     const uint32_t* __restrict__ order /* the queue's entries in the order to take them */) {
-  const uint32_t n = ctl->n_q[nq];
+  const uint32_t n = ctl->n_q_[nq].v;
   uint32_t n_nodes = 0, n_prims = 0;   // node records and leaf records this lane fetched
   WaveFeed feed = {0u, 0u, false};
   LaneStack st = lane_stack(0);
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
         if (tree) walk8_begin(w, ray);
         state = 1; have_next = false;
       }
-      const uint32_t e = feed_take(feed, &ctl->cursor_rays, !have_next, n);
+      const uint32_t e = feed_take(feed, &ctl->cursor_rays_.v, !have_next, n);
       if (e != 0xffffffffu) {
         nslot = order[e];
         nray.o = {A.ray[0][nslot], A.ray[1][nslot], A.ray[2][nslot]};
@@ -406,10 +413,10 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ BlockScratch bs;
   if (i == 0) {   // every kernel of the turn before has finished: its cursors and the counters it read are free
-    ctl->cursor_rays = 0u; ctl->cursor_shadow = 0u;
-    ctl->n_q[turn.n_zero] = 0u; ctl->n_shadow[1 - turn.sh] = 0u;
+    ctl->cursor_rays_.v = 0u; ctl->cursor_shadow_.v = 0u;
+    ctl->n_q_[turn.n_zero].v = 0u; ctl->n_shadow_[1 - turn.sh].v = 0u;
   }
-  const bool valid = i < ctl->n_q[turn.n_in];
+  const bool valid = i < ctl->n_q_[turn.n_in].v;
   uint32_t did = 0;
   bool cast = false;           // a light sample needs its visibility ray
   Ray<float> sh_ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
   }
   }
   uint32_t k, at;
-  block_append2(bs, &ctl->n_shadow[turn.sh], cast, k, &ctl->n_q[turn.n_out], live, at);
+  block_append2(bs, &ctl->n_shadow_[turn.sh].v, cast, k, &ctl->n_q_[turn.n_out].v, live, at);
   if (cast) {
     A.sh_slot[k] = sh_target;
     A.sh[0][k] = sh_ray.o.x; A.sh[1][k] = sh_ray.o.y; A.sh[2][k] = sh_ray.o.z;
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
 template <int MODE>
 __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int sh /* the shadow queue's counter */, float* __restrict__ partial, int stack_levels,
                                                      const uint32_t* __restrict__ order /* shadow-queue indices in the order to take them, or NULL = as queued */) {
-  const uint32_t n = ctl->n_shadow[sh];
+  const uint32_t n = ctl->n_shadow_[sh].v;
   WaveFeed feed = {0u, 0u, false};
   LaneStack st = lane_stack(0);
   const bool tree = MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims;
@@ -523,7 +530,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<
         if (tree) walk8_begin(w, sr);
         state = 1; have_next = false;
       }
-      const uint32_t e = feed_take(feed, &ctl->cursor_shadow, !have_next, n);
+      const uint32_t e = feed_take(feed, &ctl->cursor_shadow_.v, !have_next, n);
       if (e != 0xffffffffu) {
         ni = order ? order[e] : e;
         nsr.o = {A.sh[0][ni], A.sh[1][ni], A.sh[2][ni]};
@@ -666,7 +673,7 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
     run(&turn, grid);
     if ((iter & 7u) == 7u || live_bound < 65536u) {
       uint32_t n_live = 0;
-      if (hipMemcpyAsync(&n_live, &ctl->n_q[turn.n_out], sizeof n_live, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      if (hipMemcpyAsync(&n_live, &ctl->n_q_[turn.n_out].v, sizeof n_live, hipMemcpyDeviceToHost, stream) != hipSuccess ||
           hipStreamSynchronize(stream) != hipSuccess) { err = hipGetErrorString(hipGetLastError()); return RTX_ERR_HIP; }
       if (n_live == 0) break;
       live_bound = n_live;
