@@ -77,7 +77,9 @@ int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, cons
       hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH, 31>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     else if (!sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && sc.n_quads == 0)
       hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH, 7>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
-    else if (!sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && P.use_nee && P.use_mis && P.rng == 1 /* RNG_PCG4D */)   // quad lights: the Cornell box with its ceiling panel
+    else if (!sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && sc.n_emissive == 0 && P.use_nee && P.use_mis && P.rng == 1 /* RNG_PCG4D */)   // quad lights only: the Cornell box with its ceiling panel
+      hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH, 91>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else if (!sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && P.use_nee && P.use_mis && P.rng == 1 /* RNG_PCG4D */)
       hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH, 27>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     else if (!sc.env.valid && sc.n_points == 0 && sc.n_disks == 0)
       hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH, 3>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);

@@ -73,7 +73,8 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #endif
 // LEAN (bit mask) compiles scene features out of an instance by pinning the scene's counts to zero, so that every
 // branch on them folds away: 1 = no environment map, 2 = no point and no disk lights, 4 = no quad lights,
-// 8 = NEE and MIS on, 16 = the pcg4d generator, 32 = no material has a normal map (the tangent-frame code is left out).
+// 8 = NEE and MIS on, 16 = the pcg4d generator, 32 = no material has a normal map (the tangent-frame code is left out),
+// 64 = no emissive sphere.
 template <class R, int MODE, bool LDS_MATS, int INTEG = INTEG_PATH, int LEAN = 0>
 __global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4) ? RTX_MNEE_F32_MIN_WAVES : (MODE == MODE_FLAT ? (INTEG == INTEG_PATHPHOTON ? RTX_PHOTON_FLAT_MIN_WAVES : (LEAN & 1) ? RTX_LEAN_MIN_WAVES : (LEAN ? RTX_LEAN_ENV_MIN_WAVES : RTX_FLAT_MIN_WAVES)) : (INTEG == INTEG_PATH_MNEE ? RTX_MNEE_MIN_WAVES : (sizeof(R) == 4 ? (INTEG == INTEG_PATHPHOTON ? RTX_PHOTON_MIN_WAVES : RTX_TREE_MIN_WAVES) : 1)))) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
                                                                DCounters* __restrict__ counters, int stack_first_int) {
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4
   if constexpr ((LEAN & 4) != 0) { sc.n_quads = 0; }
   if constexpr ((LEAN & 8) != 0) { P.use_nee = 1; P.use_mis = 1; }
   if constexpr ((LEAN & 16) != 0) { P.rng = RNG_PCG4D; }
+  if constexpr ((LEAN & 64) != 0) { sc.n_emissive = 0; }
   const DMaterial<R>* mats = sc.mats;
   if constexpr (LDS_MATS) mats = stage_materials(sc);
   const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
