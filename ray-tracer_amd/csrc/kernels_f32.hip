@@ -60,7 +60,9 @@ int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, cons
     return 0;
   }
   if (L.integ == INTEG_PATH_MNEE) {   // manifold NEE: single-precision traces, the manifold walk itself in double (pt_mnee.hpp)
-    if (L.mode == MODE_FLAT && L.lds_mats) hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH_MNEE>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    if (L.mode == MODE_FLAT && L.lds_mats && !sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && sc.n_quads == 0 && P.use_nee && P.use_mis && P.rng == 1 /* RNG_PCG4D */)
+      hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH_MNEE, 31>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);   // the lean instance (see below)
+    else if (L.mode == MODE_FLAT && L.lds_mats) hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH_MNEE>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     else if (L.mode == MODE_FLAT) return -1;
     else if (L.lds_mats) hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, true, INTEG_PATH_MNEE>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     else hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, false, INTEG_PATH_MNEE>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
