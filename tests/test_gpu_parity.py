@@ -19,7 +19,7 @@ PATHPHOTON_F32_BAD_PIXELS_MAX = 0.015
 # Measured per scene on MI355X: profiles/r02_parity_rates.jsonl.
 # The walk is deterministic, so the bound is the measured count of such rays itself (grazing hits on silhouettes and edges).
 F32_ID_MISMATCH_RAYS = {"normal_mapped": 3, "kitchen_sink": 1, "soup": 1}   # of 4296 (soup: 10096) rays; every other scene: 0
-# Per-channel mean of the converged film against the reference's, relative (the criterion of the survey: 1 %).
+# Per-channel mean of the converged film against the reference's, relative: 1 %.
 CHANNEL_MEAN_TOL = 0.01
 
 
