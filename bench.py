@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: path tracing with NEE + MIS on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c5]
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c5] [--multi process|single]
 
 One "step" is one complete render of the configuration's workload:
 
@@ -10,15 +10,24 @@ One "step" is one complete render of the configuration's workload:
   c3  scenes/cornell_box_quad.json (depth 50) and scenes/caustics_test.json (depth 16, as a path tracer), 800x800, 128 spp each
   c5  the synthetic BVH stress scene: 10 M triangles, 1920x1080, 64 spp, max_depth 8
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) the image's rows are interleaved over the ranks and the
-film is gathered to rank 0 over RCCL inside the timed region; total work is fixed, so scaling is "strong".
+Run for c2 without --config, the line also carries c3 and c5, three steps each, under "configs".
 
-Rank 0 prints ONE JSON line.  `value` = samples of all ranks / max-over-ranks time.
+N > 1: the image's rows are interleaved over the GPUs and the film is gathered on the first one inside the timed region; total
+work is fixed, so scaling is "strong".  Two hosts for it:
+  --multi process (default)  one process per GPU over torch.distributed (backend nccl = RCCL).  Started plainly
+                             (`python bench.py --gpus 8`, no WORLD_SIZE in the environment) this process starts the N ranks
+                             itself, as a child `python -m torch.distributed.run`, relays rank 0's line and exits with the child's
+                             status; started by torch.distributed.run it is one of the ranks.
+  --multi single             one process, one context over the N GPUs (rtx_create_multi), no torch.distributed.
+
+Rank 0 prints ONE JSON line.  `value` = samples of all GPUs / max-over-ranks time.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,6 +53,8 @@ CONFIGS = {
     "c3": [("cornell_box_quad", 800, 800, 128, 50), ("caustics_test", 800, 800, 128, 16)],
     "c5": [("stress10m", 1920, 1080, 64, 8)],
 }
+EXTRA_CONFIGS = ("c3", "c5")     # timed after the headline when it is c2
+EXTRA_STEPS, EXTRA_WARMUP = 3, 1
 
 
 def sha256_of(path):
@@ -54,146 +65,274 @@ def sha256_of(path):
     return h.hexdigest()
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--multi", choices=["process", "single"], default="process", help="N > 1: one process per GPU (torch.distributed) or one process over all GPUs (rtx_create_multi)")
+    ap.add_argument("--device-ids", default="", help="--multi single: comma-separated device list instead of 0..N-1 (a device may repeat: rehearsal on fewer GPUs)")
+    ap.add_argument("--gather", choices=["peer", "rccl"], default="peer", help="--multi single: how the film reaches the first device")
     ap.add_argument("--spp", type=int, default=0, help="override the configuration's samples per pixel (the line then says so)")
     ap.add_argument("--pipeline", choices=["auto", "fused", "wavefront"], default="auto")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
-    ap.add_argument("--no-extras", action="store_true", help="skip the double-precision and id-agreement legs (profiling runs)")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the double-precision and id-agreement legs and the c3 / c5 lines (profiling runs)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the c3 / c5 lines only")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher rehearsal without a GPU: the ranks meet over gloo, render nothing, rank 0 prints a stub line")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count()   # counts devices without initialising one
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` started plainly: run the N ranks as a child torch.distributed.run.  The parent makes no GPU call
+    (a process that has touched the GPU must not be replaced, and needs not be: the child is a child)."""
+    if not args.dry_launch:
+        have = visible_gpus()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible on this node: nothing was started", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or args.gpus) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode   # stdout is inherited: rank 0's line is this process's line
+
+
+def dry_rank(args):
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "rank_sum": float(t.item()), "steps": args.steps, "warmup": args.warmup,
+                          "config": {"workload": "none (launcher rehearsal)", "name": args.config}}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
+class Runner:
+    """One configuration's scenes uploaded, and the step that renders them all and leaves the whole film(s) on the first GPU."""
+
+    def __init__(self, pkg, torch, dist, args, cfg, world, rank, local_rank, single_ids):
+        abi = pkg.abi
+        self.pkg, self.torch, self.dist, self.cfg = pkg, torch, dist, cfg
+        self.world, self.rank, self.single_ids = world, rank, single_ids
+        self.dev = f"cuda:{single_ids[0] if single_ids else local_rank}"
+        self.stream = torch.cuda.current_stream().cuda_stream
+        pipeline = {"auto": abi.PIPELINE_AUTO, "fused": abi.PIPELINE_FUSED, "wavefront": abi.PIPELINE_WAVEFRONT}[args.pipeline]
+        self.jobs, self.upload_s, self.stats = [], 0.0, []
+        shards = world if not single_ids else 1           # a multi-device context shards inside the library
+        for (name, W, H, spp, depth) in CONFIGS[cfg]:
+            spp = args.spp or spp
+            sd = pkg.synthetic.stress_scene(10_000_000) if name == "stress10m" else pkg.scene_loader.load(os.path.join(SCENES, name + ".json"))
+            st = sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=depth, use_nee=1, use_mis=1, seed=1234, mode=abi.MODE_PATHTRACE,
+                             precision=abi.PRECISION_F32, pipeline=pipeline, shard_index=rank if shards > 1 else 0, shard_count=shards)
+            pt = pkg.renderer.HipPathTracer(device_ids=single_ids) if single_ids else pkg.renderer.HipPathTracer(local_rank)
+            if single_ids and args.gather == "rccl":
+                pt.set_gather(abi.GATHER_RCCL)
+            pt.set_settings(st)
+            t0 = time.perf_counter()
+            pt.upload_scene(sd)                       # inputs are resident in HBM before the timed region
+            self.upload_s += time.perf_counter() - t0
+            pt.set_camera(sd.camera(W, H))
+            self.jobs.append(dict(name=name, W=W, H=H, spp=spp, depth=depth, sd=sd, pt=pt, settings=st))
+        # Process mode: every rank's rows of every scene lie in ONE buffer (parallel.ShardedFilms), so a step gathers once.
+        import importlib
+        parallel = importlib.import_module("raytracer_amd.parallel")
+        self.films = parallel.ShardedFilms([(j["H"], j["W"]) for j in self.jobs], rank if shards > 1 else 0, shards, self.dev)
+        for j, local in zip(self.jobs, self.films.local):
+            j["local"] = local
+        self.gather_events = []
+
+    def step(self):
+        """-> the films on the first GPU (None on the other ranks)."""
+        torch = self.torch
+        if self.single_ids or self.world == 1:
+            for j in self.jobs:
+                self.stats.append(j["pt"].render_device(j["local"].data_ptr(), self.stream))
+            return [j["local"] for j in self.jobs]
+        for j in self.jobs:                                   # every scene's kernels go on the stream first,
+            j["pt"].render_device_async(j["local"].data_ptr(), self.stream)
+        if self.rank == 0:                                    # then ONE gather of all of them,
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            films = self.films.gather()
+            e1.record()
+            self.gather_events.append((e0, e1))
+        else:
+            films = self.films.gather()
+        for j in self.jobs:                                   # and only then the host waits
+            self.stats.append(j["pt"].render_wait())
+        return films
+
+    def close(self):
+        for j in self.jobs:
+            j["pt"].close()
+
+
+def measure(runner, torch, dist, world, steps, warmup):
+    """W untimed steps, then exactly K steps between barrier + synchronize; -> (films, seconds = max over ranks, samples, rays)."""
+    def fence():
+        if world > 1 and not runner.single_ids:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    films = None
+    for _ in range(warmup):
+        films = runner.step()
+    runner.stats.clear()
+    runner.gather_events.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        films = runner.step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=runner.dev)
+    tot = torch.tensor([float(sum(s.samples for s in runner.stats)), float(sum(s.rays_closest + s.rays_shadow for s in runner.stats))], dtype=torch.float64,
+                       device=runner.dev)
+    if world > 1 and not runner.single_ids:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    return films, float(tt.item()), float(tot[0].item()), float(tot[1].item())
+
+
+def config_line(args, abi, runner, films, elapsed, total_samples, total_rays, steps, world, parallelism):
+    jobs = runner.jobs
+    expect = sum(j["W"] * j["H"] * j["spp"] for j in jobs) * steps
+    assert films is not None and all(tuple(f.shape) == (j["H"], j["W"], 3) for f, j in zip(films, jobs))
+    assert total_samples == float(expect), "work was skipped inside the timed region"
+    workload = " + ".join(f"{j['name']} {j['W']}x{j['H']} {j['spp']}spp max_depth={j['depth']}" for j in jobs) + " NEE+MIS mnee=off"
+    last = jobs[0]["pt"].last_stats
+    n_jobs = len(jobs)
+    mine = runner.stats                               # rank 0's (or the whole context's) statistics, scene by scene
+    kernel_s = sum(s.seconds_render for s in mine) / steps
+    out = {
+        "value": total_samples / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+        "config": {"workload": workload, "name": runner.cfg, "parallelism": parallelism,
+                   "pipeline": {abi.PIPELINE_FUSED: "fused", abi.PIPELINE_WAVEFRONT: "wavefront"}.get(last.pipeline_used, "?"),
+                   "seed": 1234, "scene_upload_and_bvh_s": runner.upload_s},
+        "mrays_per_s": total_rays / elapsed / 1e6,
+        "mrays_per_s_per_gpu": total_rays / elapsed / 1e6 / world,
+        "msamples_per_s_per_gpu": total_samples / elapsed / 1e6 / world,
+        "film_mean_clamped": [float(f.clamp(0, 1).mean().item()) for f in films],
+        # what a step spends outside this GPU's render kernels: launches, waiting for the slowest GPU, the film gather, synchronisation
+        "kernel_ms_per_step_this_gpu": kernel_s * 1e3,
+        "non_kernel_ms_per_step": (elapsed / steps - kernel_s) * 1e3,
+        "roofline": roofline(runner.cfg, abi, jobs, mine, world, n_jobs),
+    }
+    if runner.gather_events:
+        # rank 0's view: waiting for the slowest rank + the transfers + re-interleaving the rows
+        g_ms = sum(a.elapsed_time(b) for a, b in runner.gather_events) / len(runner.gather_events)
+        into_root = runner.films.bytes_into_root()
+        out["film_gather"] = {"ms_per_step_incl_wait": g_ms, "bytes_into_rank0_per_step": into_root, "gathers_per_step": 1,
+                              "GBps_lower_bound": into_root / (g_ms * 1e-3) / 1e9 if g_ms > 0 else None}
+    elif world > 1:
+        out["film_gather"] = {"inside": "rtx_render_device of the multi-device context (rtx_create_multi)", "mode": args.gather,
+                              "bytes_into_device0_per_step": sum((j["H"] - len(range(0, j["H"], world))) * j["W"] * 3 * 4 for j in jobs)}
+    return out
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    in_rank = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and args.multi == "process" and not in_rank:
+        sys.exit(launch_ranks(args, argv))
+    if args.dry_launch:
+        sys.exit(dry_rank(args) if in_rank else print(json.dumps({"dry_launch": True, "n_gpus": 1})) or 0)
+
+    single_ids = None
+    if args.multi == "single" and (args.gpus > 1 or args.device_ids):
+        single_ids = [int(v) for v in args.device_ids.split(",")] if args.device_ids else list(range(args.gpus))
+        if len(single_ids) != args.gpus:
+            raise SystemExit(f"--device-ids lists {len(single_ids)} devices, --gpus says {args.gpus}")
+    if not in_rank:
+        need = (max(single_ids) + 1) if single_ids else 1
+        have = visible_gpus()
+        if have < need:
+            print(f"bench.py: {need} GPU(s) needed, {have} visible on this node: nothing was started", file=sys.stderr)
+            sys.exit(2)
 
     import numpy as np
     import torch
     import torch.distributed as dist
     import rtx_pkg
     pkg = rtx_pkg.load()
-    import importlib
-    parallel = importlib.import_module("raytracer_amd.parallel")
     abi = pkg.abi
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if not single_ids else args.gpus
+    rank = int(os.environ.get("RANK", "0")) if not single_ids else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if not single_ids else single_ids[0]
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} disagrees with WORLD_SIZE {world}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 and not single_ids:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    parallelism = ("single GPU" if world == 1 else
+                   f"row-interleaved x{world}, one process over all GPUs (rtx_create_multi, devices {single_ids}), film gather by {'RCCL send/recv' if args.gather == 'rccl' else 'peer copies'}" if single_ids else
+                   f"row-interleaved x{world}, one process per GPU, one film gather per step over RCCL")
 
-    pipeline = {"auto": abi.PIPELINE_AUTO, "fused": abi.PIPELINE_FUSED, "wavefront": abi.PIPELINE_WAVEFRONT}[args.pipeline]
-    stream = torch.cuda.current_stream().cuda_stream
-    jobs = []   # one per scene of the configuration: tracer, scene, film tensor, sizes
-    upload_s = 0.0
-    for (name, W, H, spp, depth) in CONFIGS[args.config]:
-        spp = args.spp or spp
-        sd = pkg.synthetic.stress_scene(10_000_000) if name == "stress10m" else pkg.scene_loader.load(os.path.join(SCENES, name + ".json"))
-        st = sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=depth, use_nee=1, use_mis=1, seed=1234, mode=abi.MODE_PATHTRACE,
-                         precision=abi.PRECISION_F32, pipeline=pipeline, shard_index=rank, shard_count=world)
-        pt = pkg.renderer.HipPathTracer(local_rank)
-        pt.set_settings(st)
-        t0 = time.perf_counter()
-        pt.upload_scene(sd)                       # inputs are resident in HBM before the timed region
-        upload_s += time.perf_counter() - t0
-        pt.set_camera(sd.camera(W, H))
-        rows = parallel.shard_rows(H, rank, world)
-        local = torch.empty((rows, W, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
-        jobs.append(dict(name=name, W=W, H=H, spp=spp, depth=depth, sd=sd, pt=pt, local=local, settings=st))
+    runner = Runner(pkg, torch, dist, args, args.config, world, rank, local_rank, single_ids)
+    films, elapsed, total_samples, total_rays = measure(runner, torch, dist, world, args.steps, args.warmup)
+    out = None
+    if rank == 0:
+        head = config_line(args, abi, runner, films, elapsed, total_samples, total_rays, args.steps, world, parallelism)
+        out = {"metric": "Msamples/s (NEE+MIS path tracing; Mrays/s alongside)", "value": head.pop("value"), "unit": head.pop("unit"),
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head.pop("ms_per_step"),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic (scenes built from the reference's scene descriptions / generated in code; no image assets)"}
+        head.pop("steps")
+        out.update(head)
+        if world == 1 and not args.no_extras:
+            out["f64"] = f64_leg(pkg, runner.jobs[0])
+            out["id_mismatch_f32"] = id_mismatch_leg(pkg, np, runner.jobs[0])
+    runner.close()
+    del runner, films
 
-    stats = []
-    gather_events = []   # rank 0, N > 1: the film gather of every timed step, bracketed by events on torch's stream
-
-    def step():
-        films = []
-        for j in jobs:
-            s = j["pt"].render_device(j["local"].data_ptr(), stream)   # kernels on torch's current stream; returns when they are done
-            stats.append(s)
-            if world == 1:
-                films.append(parallel.gather_film(j["local"], j["H"], j["W"], rank, world))
-                continue
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            films.append(parallel.gather_film(j["local"], j["H"], j["W"], rank, world))
-            e1.record()
-            gather_events.append((e0, e1))
-        return films
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    films = None
-    for _ in range(args.warmup):
-        films = step()
-    stats.clear()
-    gather_events.clear()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        films = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-    tot = torch.tensor([float(sum(s.samples for s in stats)), float(sum(s.rays_closest + s.rays_shadow for s in stats))], dtype=torch.float64,
-                       device=f"cuda:{local_rank}")
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed = float(tt.item())
-    total_samples, total_rays = float(tot[0].item()), float(tot[1].item())
+    # The other configurations, three steps each, in the same line (the headline above is untouched by them).
+    if args.config == "c2" and not args.no_extras and not args.no_configs:
+        extras = {}
+        for cfg in EXTRA_CONFIGS:
+            r2 = Runner(pkg, torch, dist, args, cfg, world, rank, local_rank, single_ids)
+            f2, e2, s2, y2 = measure(r2, torch, dist, world, EXTRA_STEPS, EXTRA_WARMUP)
+            if rank == 0:
+                line = config_line(args, abi, r2, f2, e2, s2, y2, EXTRA_STEPS, world, parallelism)
+                line["warmup"] = EXTRA_WARMUP
+                if cfg == "c5" and world == 1:
+                    line["id_mismatch_f32"] = id_mismatch_leg(pkg, np, r2.jobs[0])
+                extras[cfg] = line
+            r2.close()
+            del r2, f2
+        if rank == 0:
+            out["configs"] = extras
 
     if rank == 0:
-        expect = sum(j["W"] * j["H"] * j["spp"] for j in jobs) * args.steps
-        assert films is not None and all(tuple(f.shape) == (j["H"], j["W"], 3) for f, j in zip(films, jobs))
-        assert total_samples == float(expect), "work was skipped inside the timed region"
-        workload = " + ".join(f"{j['name']} {j['W']}x{j['H']} {j['spp']}spp max_depth={j['depth']}" for j in jobs) + " NEE+MIS mnee=off"
-        last = jobs[0]["pt"].last_stats
-        out = {
-            "metric": "Msamples/s (NEE+MIS path tracing; Mrays/s alongside)",
-            "value": total_samples / elapsed / 1e6,
-            "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic (scenes built from the reference's scene descriptions / generated in code; no image assets)",
-            "config": {"workload": workload, "name": args.config,
-                       "parallelism": f"row-interleaved x{world}, film gather over RCCL" if world > 1 else "single GPU",
-                       "pipeline": {abi.PIPELINE_FUSED: "fused", abi.PIPELINE_WAVEFRONT: "wavefront"}.get(last.pipeline_used, "?"),
-                       "seed": 1234, "scene_upload_and_bvh_s": upload_s},
-            "mrays_per_s": total_rays / elapsed / 1e6,
-            "mrays_per_s_per_gpu": total_rays / elapsed / 1e6 / world,
-            "msamples_per_s_per_gpu": total_samples / elapsed / 1e6 / world,
-            "film_mean_clamped": [float(f.clamp(0, 1).mean().item()) for f in films],
-            "roofline": roofline(args, abi, jobs, stats, world),
-        }
-        if world > 1 and gather_events:
-            # rank 0's view: waiting for the slowest rank + the transfers + re-interleaving the rows
-            g_ms = sum(a.elapsed_time(b) for a, b in gather_events) / len(gather_events)
-            into_root = sum((world - 1) * parallel.shard_rows(j["H"], 0, world) * j["W"] * 3 * 4 for j in jobs) / len(jobs)
-            out["film_gather"] = {"ms_per_render_incl_wait": g_ms, "bytes_into_rank0": into_root,
-                                  "GBps_lower_bound": into_root / (g_ms * 1e-3) / 1e9 if g_ms > 0 else None}
-        if world == 1 and not args.no_extras:
-            out["f64"] = f64_leg(pkg, jobs[0])
-            out["id_mismatch_f32"] = id_mismatch_leg(pkg, np, jobs[0])
         if world == 1 and args.cpu_baseline_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(pkg, jobs[0], args)
+            job0 = dict(name=CONFIGS[args.config][0][0], depth=CONFIGS[args.config][0][4])
+            out["cpu_baseline"] = cpu_baseline(pkg, job0, args)
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline"]["gpu_over_cpu_note"] = "Msamples/s of the full-size GPU workload over Msamples/s of the CPU sample (reduced resolution, this job's share of the host's cores); a reported ratio, not vs_baseline"
         print(json.dumps(out), flush=True)
-    for j in jobs:
-        j["pt"].close()
-    if world > 1:
+    if world > 1 and not single_ids:
         dist.destroy_process_group()
 
 
-def roofline(args, abi, jobs, stats, world):
+def roofline(cfg, abi, jobs, stats, world, n_jobs):
     """The dominant kernel of rank 0's launches against the ceiling that bounds it.
 
     Fused pipeline (c2, c3): the scene sits in scalar registers and the path in vector registers, HBM sees next to nothing:
@@ -210,7 +349,7 @@ def roofline(args, abi, jobs, stats, world):
     reached the L2's memory side in the profile, FETCH_SIZE as tallied + WRITE_SIZE (the counter tallies 64 bytes per request,
     exact for scattered 64-byte records, half the truth for streaming reads: scripts/gather_calib.sh); the difference to the
     record bytes is what the caches served."""
-    first = [s for i, s in enumerate(stats) if i % len(jobs) == 0]   # scene 0 of every step
+    first = [s for i, s in enumerate(stats) if i % n_jobs == 0]   # scene 0 of every step
     n = len(first)
     seg = sum(s.segments for s in first) / n
     shd = sum(s.rays_shadow for s in first) / n
@@ -221,7 +360,7 @@ def roofline(args, abi, jobs, stats, world):
     prof = None
     try:
         allp = json.load(open(os.path.join(ROOT, "profiles", "bench_profiles.json")))
-        cand = allp.get(args.config)
+        cand = allp.get(cfg)
         if cand and cand.get("workload") == workload and cand.get("lib_sha256") == sha256_of(abi.LIB_PATH):
             prof = cand
     except (OSError, ValueError):
@@ -326,7 +465,6 @@ def cpu_baseline(pkg, job, args):
     where the launcher sets it (a one-GPU box hands 16 of the host's cores to a job and asks for pools of that size), else the
     CPUs this process may run on."""
     import re
-    import subprocess
     import tempfile
     try:
         allowed = len(os.sched_getaffinity(0))
@@ -354,7 +492,7 @@ def cpu_baseline(pkg, job, args):
             print(f"reference baseline failed ({e}); falling back to the port", file=sys.stderr)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
-    sd = job["sd"]
+    sd = pkg.synthetic.stress_scene(10_000_000) if name == "stress10m" else pkg.scene_loader.load(scene_file)
     osc = O.OracleScene(sd)
     cam = sd.camera(W, H)
     probe_spp = 4

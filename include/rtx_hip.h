@@ -196,6 +196,16 @@ int rtx_create_multi(rtx_ctx** out_ctx, const int* device_ids, int n_devices);
  * j / n_devices. */
 int rtx_multi_shard(int shard_index, int shard_count, int device_rank, int n_devices, int* out_index, int* out_count);
 
+/* How a multi-device context brings the devices' rows into the film of rtx_render_device (device memory of device_ids[0]):
+ * RTX_GATHER_PEER_COPY (default): one hipMemcpyPeerAsync per device into a staging buffer on the first device, ordered behind that
+ * device's render by an event, then one strided copy there; RTX_GATHER_RCCL: grouped ncclSend / ncclRecv into the first device over
+ * one communicator per device (ncclCommInitAll), RCCL being loaded with dlopen("librccl.so.1") on this call, so the library itself
+ * does not depend on it.  The film is the same bit for bit.  RCCL needs every device listed once; a list with repeats is refused
+ * (RTX_ERR_UNSUPPORTED), a missing library too.  Host-memory output (rtx_render) is copied by every device over its own host
+ * link in both modes. */
+enum { RTX_GATHER_PEER_COPY = 0, RTX_GATHER_RCCL = 1 };
+int rtx_multi_set_gather(rtx_ctx* ctx, int mode);
+
 /* Replaces GPUPathTracer::upload_scene (cuda_api.hpp:84-89; cuda_pathtracer.cu:234-318).
  * Copies the description, builds both BVHs (the reference-order binary tree of
  * engine/bvh.hpp:148-218 for validation, and the wide one the integrator traverses) and
@@ -218,16 +228,27 @@ int rtx_render(rtx_ctx* ctx, const rtx_settings* settings, float* out_rgb, rtx_s
  * kernels have finished (stats need the device counters). */
 int rtx_render_device(rtx_ctx* ctx, const rtx_settings* settings, void* d_out_rgb, void* hip_stream, rtx_stats* stats);
 
+/* rtx_render_device in two halves, for callers that want the host back while the GPU renders (a second scene on another context,
+ * a film gather of the previous frame).  It has no counterpart in the reference, whose GPUPathTracer::render is synchronous
+ * (cuda_pathtracer.cu:375).  rtx_render_device_async puts the render on `hip_stream` (not NULL: the caller must be able to order
+ * its own work behind it) and returns without waiting; the film is complete where the stream stands at that moment.  The fused
+ * pipeline enqueues and returns at once; the queue-based pipeline reads its queue lengths back between kernels, so the call
+ * returns when its last kernels are enqueued.  rtx_render_wait waits for that render and fills `stats` (may be NULL).  A context
+ * holds ONE render in flight: any other render call on it first waits for the one pending.  Single-device contexts only. */
+int rtx_render_device_async(rtx_ctx* ctx, const rtx_settings* settings, void* d_out_rgb, void* hip_stream);
+int rtx_render_wait(rtx_ctx* ctx, rtx_stats* stats);
+
 /* rtx_render_device for callers that cannot allocate device memory while they run: code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  It allocates nothing (no hipMalloc /
  * hipFree, no allocating library routine): the chunk sums and counters of the render live in a 64 MiB array that is part of the
  * library's code object on every GPU (held until the process ends), and the kernels are the ones rtx_render_device launches,
  * so the film is the same bit for bit.  Limits, each refused with a message: single precision, RTX_MODE_PATHTRACE or
- * RTX_MODE_WHITTED, the fused pipeline (RTX_PIPELINE_AUTO must resolve to it: scenes of at most 12 bounded primitives, or
- * pipeline = RTX_PIPELINE_FUSED with a tree of at most 6 levels), use_mnee = 0, and
+ * RTX_MODE_WHITTED, the fused pipeline (RTX_PIPELINE_AUTO must resolve to it: scenes of at most 12 bounded primitives; larger
+ * scenes with pipeline = RTX_PIPELINE_FUSED), use_mnee = 0, and
  * rows_of_shard * width * chunks * 12 bytes <= 64 MiB - 256, chunks = min(samples_per_pixel, 16) (e.g. 640x360 at any sample
- * count, 1920x1080 at 2 samples per pixel).  With stats = NULL the call only enqueues work on `hip_stream` (NULL = the context's
- * stream) and returns; with stats it also waits for the kernels and fills them.  Every call on one GPU uses that GPU's one
+ * count, 1920x1080 at 2 samples per pixel).  With stats = NULL the call only enqueues kernels on `hip_stream` (NULL = the context's
+ * stream) and returns - no event, no copy, no memset node: the form a caller records into a HIP graph; with stats it also
+ * times the kernels with events, waits for them and fills the statistics.  Every call on one GPU uses that GPU's one
  * array: calls that overlap in time on the same GPU (other contexts, other streams) race; calls on one stream do not. */
 int rtx_render_device_noalloc(rtx_ctx* ctx, const rtx_settings* settings, void* d_out_rgb, void* hip_stream, rtx_stats* stats);
 

@@ -111,6 +111,7 @@ PRECISION_F32, PRECISION_F64 = 0, 1
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
 MODE_WHITTED, MODE_PATHTRACE, MODE_BDPT, MODE_PATHPHOTON = 0, 1, 2, 6
 RNG_AUTO, RNG_PHILOX, RNG_PCG4D = 0, 1, 2
+GATHER_PEER_COPY, GATHER_RCCL = 0, 1
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 
@@ -125,6 +126,9 @@ EXPORTS = {
     "rtx_set_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
     "rtx_render": (C.c_int, [C.c_void_p, C.POINTER(Settings), C.POINTER(C.c_float), C.POINTER(Stats)]),
     "rtx_render_device": (C.c_int, [C.c_void_p, C.POINTER(Settings), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
+    "rtx_render_device_async": (C.c_int, [C.c_void_p, C.POINTER(Settings), C.c_void_p, C.c_void_p]),
+    "rtx_render_wait": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "rtx_multi_set_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "rtx_render_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(Settings), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "rtx_postprocess": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_uint8)]),
     "rtx_postprocess_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]),

@@ -46,6 +46,7 @@ bool WavefrontPool::mark(hipStream_t stream) {
 }
 double WavefrontPool::timed_seconds() const {
   double s = 0.0;
+  if (!timing_ok) return 0.0;
   for (size_t i = 0; i + 1 < events_used; i += 2) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, events[i], events[i + 1]) == hipSuccess) s += ms * 1e-3;

@@ -147,8 +147,9 @@ struct WavefrontPool {
   // HIP events around every launch of the closest-hit traversal kernel of the last render (pairs: before, after)
   std::vector<hipEvent_t> events;
   size_t events_used = 0;
+  bool timing_ok = true;             // every mark of the last render succeeded (else its pairs would be mismatched)
   bool mark(hipStream_t stream);     // record the next event on `stream`
-  double timed_seconds() const;      // sum over the pairs; call after the stream has been synchronised
+  double timed_seconds() const;      // sum over the pairs (0 if a mark failed); call after the stream has been synchronised
   void release();
 };
 int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* d_film,

@@ -10,6 +10,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <dlfcn.h>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -83,12 +87,99 @@ unsigned char* scratch_pointer(int device) {
 
 struct rtx_ctx;
 static size_t stack_words(const rtx_ctx* c, bool f64);
+
+namespace {
+// A host thread that runs one job at a time, kept for the life of a multi-device context: a render hands every other device's
+// share to that device's worker instead of starting a thread per call.
+class Worker {
+ public:
+  Worker() : th_([this] { run(); }) {}
+  ~Worker() {
+    { std::lock_guard<std::mutex> l(m_); quit_ = true; }
+    cv_.notify_all();
+    th_.join();
+  }
+  Worker(const Worker&) = delete;
+  Worker& operator=(const Worker&) = delete;
+  void post(std::function<void()> job) {
+    { std::lock_guard<std::mutex> l(m_); job_ = std::move(job); busy_ = true; }
+    cv_.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> l(m_);
+    cv_.wait(l, [&] { return !busy_; });
+  }
+
+ private:
+  void run() {
+    std::unique_lock<std::mutex> l(m_);
+    for (;;) {
+      cv_.wait(l, [&] { return quit_ || (busy_ && job_); });
+      if (quit_) return;
+      std::function<void()> j = std::move(job_);
+      job_ = nullptr;
+      l.unlock();
+      j();   // jobs catch their own exceptions
+      l.lock();
+      busy_ = false;
+      cv_.notify_all();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::function<void()> job_;
+  bool busy_ = false, quit_ = false;
+  std::thread th_;   // last: the thread starts when every other member exists
+};
+
+// RCCL, bound at run time (rtx_multi_set_gather): the library is not linked against it.
+struct Rccl {
+  void* handle = nullptr;
+  int (*CommInitAll)(void**, int, const int*) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  static constexpr int kFloat = 7;   // ncclFloat32 (rccl.h)
+};
+std::mutex g_rccl_mutex;
+Rccl g_rccl;
+// nullptr + *why when the library or one of its symbols is missing
+const Rccl* load_rccl(std::string* why) {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  if (g_rccl.handle) return &g_rccl;
+  void* h = nullptr;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (h) break;
+  }
+  if (!h) { if (why) { const char* e = dlerror(); *why = std::string("librccl.so.1 could not be loaded: ") + (e ? e : "?"); } return nullptr; }
+  Rccl r;
+  bool ok = true;
+  auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) { ok = false; if (why) *why = std::string("librccl lacks ") + n; } return p; };
+  r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+  r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+  r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+  r.Send = (decltype(r.Send))sym("ncclSend");
+  r.Recv = (decltype(r.Recv))sym("ncclRecv");
+  r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+  if (!ok) { dlclose(h); return nullptr; }
+  r.handle = h;
+  g_rccl = r;
+  return &g_rccl;
+}
+}  // namespace
+
 struct rtx_ctx {
   int device = 0;
   unsigned char* scratch_dev = nullptr;   // this device's copy of `scratch`
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;
   int n_cus = 256;
+  size_t lds_per_block = 65536;           // dynamic LDS one workgroup may ask for on this device
   bool has_scene = false, has_camera = false;
   HostScene scene;          // device-resident copies + BVHs
   DCamera<float> cam_f;
@@ -106,15 +197,30 @@ struct rtx_ctx {
     unsigned long long closest = 0;     // closest-hit queries the photon pass made
   } ph_map;
   unsigned long long scene_generation = 0;   // counts rtx_upload_scene calls
+  // The render whose kernels are enqueued and whose statistics have not been read yet (render_enqueue -> render_collect).
+  // Its counters arrive in h_counters, pinned host memory, so that the copy does not hold the host up.
+  DCounters* h_counters = nullptr;
+  struct Pending {
+    bool active = false;
+    hipStream_t stream = nullptr;
+    bool photon_map_reused = false, wavefront = false, f64 = false;
+    int pipeline = 0;
+    std::chrono::steady_clock::time_point wall0;
+    rtx_stats st;   // what is known when the kernels are enqueued
+  } pending;
   // Multi-device context (rtx_create_multi): this is the context of the first listed device; `peers` are the contexts of the
-  // others (owned), `gather` holds the peers' rows on this device until they are interleaved into the caller's film.
+  // others (owned), each with a host thread of its own (`workers`, same order); `gather` holds the peers' rows on this device
+  // until they are interleaved into the caller's film.
   bool multi = false;
   std::vector<rtx_ctx*> peers;
+  std::vector<std::unique_ptr<Worker>> workers;
   DeviceBuffer gather;
+  int gather_mode = RTX_GATHER_PEER_COPY;
+  std::vector<void*> comms;   // RTX_GATHER_RCCL: one communicator per device, this context's first
 };
 
 // Words of LDS per lane the traversal stack of a launch needs (0: the scene is tested linearly): the double-precision kernels
-// walk the reference's binary tree (kStackDepth), the single-precision ones the eight-wide tree (one three-word entry per level).
+// walk the reference's binary tree (kStackDepth), the single-precision ones the eight-wide tree (one two-word entry per level, walk_stack_slots).
 static size_t stack_words(const rtx_ctx* c, bool f64) {
   if (c->scene.n_prims <= kLinearMaxPrims) return 0;
   return f64 ? (size_t)kStackDepth : (size_t)walk_stack_slots(c->scene.wide.levels);
@@ -290,11 +396,16 @@ static int create_impl(rtx_ctx** out_ctx, int device_id) {
   c->device = device_id;
   c->scratch_dev = scratch_dev;
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount;
-  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->evm) != hipSuccess) {
-    delete c;
-    return fail(RTX_ERR_HIP, "stream/event creation failed");
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+    c->n_cus = prop.multiProcessorCount;
+    if (prop.sharedMemPerBlock > 0) c->lds_per_block = prop.sharedMemPerBlock;
   }
+  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->evm) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_counters, sizeof(DCounters), hipHostMallocDefault) != hipSuccess) {
+    (void)rtx_destroy(c);
+    return fail(RTX_ERR_HIP, "stream / event / pinned-memory creation failed");
+  }
+  memset(c->h_counters, 0, sizeof(DCounters));
   *out_ctx = c;
   return RTX_OK;
 }
@@ -314,6 +425,7 @@ int rtx_create_multi(rtx_ctx** out_ctx, const int* device_ids, int n_devices) {
       rc = create_impl(&p, device_ids[k]);
       if (rc != RTX_OK) { const std::string msg = g_error; (void)rtx_destroy(first); g_error = msg; return rc; }
       first->peers.push_back(p);
+      first->workers.emplace_back(new Worker());
       // direct access lets the gather copy run device to device over the links between the GPUs; without it the runtime stages
       // the same copy through the host, so a refusal is not an error
       if (p->device != first->device) {
@@ -344,11 +456,19 @@ int rtx_multi_shard(int shard_index, int shard_count, int device_rank, int n_dev
 
 int rtx_destroy(rtx_ctx* c) {
   if (!c) return RTX_OK;
+  c->workers.clear();   // joins the peers' host threads (none has a job: every render call waits for its own)
+  if (!c->comms.empty()) {
+    if (const Rccl* r = load_rccl(nullptr))
+      for (void* comm : c->comms) if (comm) (void)r->CommDestroy(comm);
+    c->comms.clear();
+  }
   for (rtx_ctx* p : c->peers) (void)rtx_destroy(p);
   c->peers.clear();
   (void)hipSetDevice(c->device);
+  if (c->pending.active && c->pending.stream) (void)hipStreamSynchronize(c->pending.stream);
+  c->pending.active = false;
   c->gather.release();
-  (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->scene.release();
   c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release(); c->post_in.release(); c->post_out.release(); c->bdpt_store.release();
   c->ph_lights.release(); c->ph_targets.release(); c->ph_out.release(); c->ph_nodes.release(); c->ph_data.release(); c->ph_boxes.release(); c->ph_cand.release();
@@ -357,12 +477,16 @@ int rtx_destroy(rtx_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->evm) (void)hipEventDestroy(c->evm);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->h_counters) (void)hipHostFree(c->h_counters);
   delete c;
   return RTX_OK;
 }
 
+static void settle(rtx_ctx* c);
 static int upload_impl(rtx_ctx* c, const rtx_scene_desc* d) {
   if (!c || !d) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+  settle(c);
+  for (rtx_ctx* p : c->peers) settle(p);
   c->has_scene = false;
   for (rtx_ctx* p : c->peers) p->has_scene = false;
   ++c->scene_generation;
@@ -465,10 +589,44 @@ int rtx_get_reference_bvh(rtx_ctx* c, rtx_bvh_node* nodes, size_t n_nodes, int32
   });
 }
 
-// `no_alloc`: the render may not allocate (rtx_render_device_noalloc): its chunk sums and counters go to the device's scratch
-// array, and whatever would need another buffer is refused.
-static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, rtx_stats* stats, bool no_alloc = false) {
+// Second half of a render: waits for the kernels render_enqueue put on the stream and turns the counters and event times into
+// statistics.
+static int render_collect(rtx_ctx* c, rtx_stats* stats) {
+  if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+  rtx_ctx::Pending& pd = c->pending;
+  if (!pd.active) return fail(RTX_ERR_NOT_READY, "no render in flight on this context");
+  pd.active = false;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(pd.stream));
+  rtx_stats st = pd.st;
+  const DCounters hc = *c->h_counters;
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  st.samples = hc.samples; st.rays_closest = hc.closest; st.rays_shadow = hc.shadow; st.segments = hc.segments;
+  if (pd.photon_map_reused) st.rays_closest += c->ph_map.closest;   // the queries this film's photon map was traced with, made by an earlier call
+  st.nodes_visited = hc.nodes_visited; st.prims_tested = hc.prims_tested;
+  if (pd.wavefront) st.seconds_extend = c->wf.timed_seconds();
+  st.seconds_render = ms * 1e-3;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->evm));
+  st.seconds_main_kernel = ms * 1e-3;
+  st.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - pd.wall0).count();
+  st.pipeline_used = (uint32_t)pd.pipeline;
+  st.precision_used = pd.f64 ? RTX_PRECISION_F64 : RTX_PRECISION_F32;
+  if (stats) *stats = st;
+  return RTX_OK;
+}
+// A context holds one render in flight: whatever touches its buffers next waits for it first (its statistics are dropped).
+static void settle(rtx_ctx* c) {
+  if (c && c->pending.active) (void)render_collect(c, nullptr);
+}
+
+// First half of a render: validates, sizes the buffers and puts every kernel (and the copies of the film to `host_out` and of the
+// counters to pinned host memory) on the stream; render_collect finishes it.  `no_alloc`: the render may not allocate
+// (rtx_render_device_noalloc): its chunk sums and counters go to the device's scratch array, and whatever would need another
+// buffer is refused; with `bare` as well it records nothing but kernels (no event, no copy) and leaves nothing to collect.
+static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, bool no_alloc = false, bool bare = false) {
   if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
+  settle(c);
   if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "render before upload_scene");
   if (!c->has_camera) return fail(RTX_ERR_NOT_READY, "render before set_camera");
   if (s->width <= 0 || s->height <= 0 || s->samples_per_pixel <= 0 || s->max_depth < 0)
@@ -508,7 +666,18 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
   const unsigned long long npix = (unsigned long long)P.rows * P.width;
   rtx_stats st;
   memset(&st, 0, sizeof st);
-  if (npix == 0) { if (stats) *stats = st; return RTX_OK; }
+  auto arm = [&](int pipeline_used, bool is_f64, bool reused) {   // hands the render over to render_collect
+    rtx_ctx::Pending& pd = c->pending;
+    pd.active = true; pd.stream = stream; pd.photon_map_reused = reused; pd.wavefront = pipeline_used == RTX_PIPELINE_WAVEFRONT; pd.f64 = is_f64;
+    pd.pipeline = pipeline_used; pd.wall0 = wall0; pd.st = st;
+  };
+  if (npix == 0) {   // a shard without rows: nothing to launch, empty statistics
+    if (bare) return RTX_OK;
+    memset(c->h_counters, 0, sizeof(DCounters));
+    HIP_TRY(hipEventRecord(c->ev0, stream)); HIP_TRY(hipEventRecord(c->evm, stream)); HIP_TRY(hipEventRecord(c->ev1, stream));
+    arm(s->pipeline == RTX_PIPELINE_WAVEFRONT ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED, s->precision == RTX_PRECISION_F64, false);
+    return RTX_OK;
+  }
   // Manifold next event estimation runs in the fused kernels: in double precision as the reference computes it, in single
   // precision with single-precision traces around a double-precision manifold walk.
   const bool whitted = s->mode == RTX_MODE_WHITTED;
@@ -550,7 +719,7 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
 
   const bool needs_stack = c->scene.n_prims > kLinearMaxPrims;
   bool photon_map_reused = false;
-  if (!photon) HIP_TRY(hipEventRecord(c->ev0, stream));   // PathPhoton records it behind its photon pass
+  if (!photon && !bare) HIP_TRY(hipEventRecord(c->ev0, stream));   // PathPhoton records it behind its photon pass
   if (pipeline == RTX_PIPELINE_FUSED) {
     const size_t elem = f64 ? sizeof(double) : sizeof(float);
     const unsigned long long items = npix * (unsigned long long)P.n_chunks;
@@ -576,6 +745,12 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
     L.stack_first_int = L.lds_mats ? (int)((mat_bytes / 4 + 3) & ~(size_t)3) : 0;
     const bool stack = L.mode != MODE_FLAT && needs_stack;
     L.lds_bytes = ((size_t)L.stack_first_int + (stack ? stack_words(c, f64) * kBlock : 0)) * sizeof(int);
+    if (L.lds_bytes > c->lds_per_block && L.lds_mats && stack) {   // the traversal stacks come first: the material table stays in device memory
+      L.lds_mats = false; L.mode = MODE_TREE_UV; L.stack_first_int = 0;
+      L.lds_bytes = stack_words(c, f64) * kBlock * sizeof(int);
+    }
+    if (L.lds_bytes > c->lds_per_block)
+      return fail(RTX_ERR_UNSUPPORTED, "this scene's traversal stacks need %zu bytes of LDS per workgroup, the device gives %zu", L.lds_bytes, c->lds_per_block);
     // Persistent grid: enough workgroups to fill every CU at the kernel's occupancy, no more.
     const int blocks_per_cu = stack ? 3 : 6;
     L.grid = (int)std::min<unsigned long long>((items + kBlock - 1) / kBlock, (unsigned long long)c->n_cus * blocks_per_cu);
@@ -613,55 +788,54 @@ static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void*
       if (!c->bdpt_store.ensure((size_t)((unsigned long long)L.grid * kBlock * per_lane))) return fail(RTX_ERR_OUT_OF_MEMORY, "BDPT light-vertex store (%llu bytes)", (unsigned long long)L.grid * kBlock * per_lane);
       if (f64) lrc = launch_render_bdpt(c->scene.dev_d, c->cam_d, P, (double*)partial_ptr, counters_ptr, L, (double*)c->bdpt_store.ptr, cap, stream);
       else lrc = launch_render_bdpt(scf, c->cam_f, P, (float*)partial_ptr, counters_ptr, L, (float*)c->bdpt_store.ptr, cap, stream);
-      HIP_TRY(hipEventRecord(c->evm, stream));
+      if (!bare) HIP_TRY(hipEventRecord(c->evm, stream));
       if (f64) launch_film_reduce((const double*)partial_ptr, d_film, npix, P.n_chunks, P.spp, stream);
       else launch_film_reduce((const float*)partial_ptr, d_film, npix, P.n_chunks, P.spp, stream);
     } else if (f64) {
       lrc = launch_render_fused(c->scene.dev_d, c->cam_d, P, (double*)partial_ptr, counters_ptr, L, stream);
-      HIP_TRY(hipEventRecord(c->evm, stream));
+      if (!bare) HIP_TRY(hipEventRecord(c->evm, stream));
       launch_film_reduce((const double*)partial_ptr, d_film, npix, P.n_chunks, P.spp, stream);
     } else {
       lrc = launch_render_fused(scf, c->cam_f, P, (float*)partial_ptr, counters_ptr, L, stream);
-      HIP_TRY(hipEventRecord(c->evm, stream));
+      if (!bare) HIP_TRY(hipEventRecord(c->evm, stream));
       launch_film_reduce((const float*)partial_ptr, d_film, npix, P.n_chunks, P.spp, stream);
     }
     if (lrc != 0) return fail(RTX_ERR_UNSUPPORTED, "no kernel instance for mode %d", L.mode);
     st.kernel_launches = photon ? 3 : 2;
   } else {
     std::string err;
+    if (stack_words(c, false) * kBlock * sizeof(int) > c->lds_per_block)
+      return fail(RTX_ERR_UNSUPPORTED, "this scene's traversal stacks need %zu bytes of LDS per workgroup, the device gives %zu", stack_words(c, false) * kBlock * sizeof(int), c->lds_per_block);
     int rc = wavefront_render(c->wf, c->scene.dev_f, c->cam_f, P, d_film, counters_ptr, c->n_cus, c->scene.fused_mode(false), (int)stack_words(c, false), stream, st.kernel_launches, err);
     if (rc != RTX_OK) return fail(rc, "wavefront: %s", err.c_str());
     HIP_TRY(hipEventRecord(c->evm, stream));
   }
-  HIP_TRY(hipEventRecord(c->ev1, stream));
   HIP_TRY(hipGetLastError());
-  if (no_alloc && !stats) return RTX_OK;   // enqueued only: the caller synchronises its stream
-  DCounters hc;
-  HIP_TRY(hipMemcpyAsync(&hc, counters_ptr, sizeof hc, hipMemcpyDeviceToHost, stream));
+  if (bare) return RTX_OK;   // kernels only: the caller synchronises (or replays) its stream
+  HIP_TRY(hipEventRecord(c->ev1, stream));
+  HIP_TRY(hipMemcpyAsync(c->h_counters, counters_ptr, sizeof(DCounters), hipMemcpyDeviceToHost, stream));
   if (host_out) HIP_TRY(hipMemcpyAsync(host_out, d_film, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-  st.samples = hc.samples; st.rays_closest = hc.closest; st.rays_shadow = hc.shadow; st.segments = hc.segments;
-  if (photon_map_reused) st.rays_closest += c->ph_map.closest;   // the queries this film's photon map was traced with, made by an earlier call
-  st.nodes_visited = hc.nodes_visited; st.prims_tested = hc.prims_tested;
-  if (pipeline == RTX_PIPELINE_WAVEFRONT) st.seconds_extend = c->wf.timed_seconds();
-  st.seconds_render = ms * 1e-3;
-  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->evm));
-  st.seconds_main_kernel = ms * 1e-3;
-  st.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
-  st.pipeline_used = (uint32_t)pipeline;
-  st.precision_used = f64 ? RTX_PRECISION_F64 : RTX_PRECISION_F32;
-  if (stats) *stats = st;
+  arm(pipeline, f64, photon_map_reused);
   return RTX_OK;
+}
+
+static int render_impl(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, rtx_stats* stats, bool no_alloc = false) {
+  const bool bare = no_alloc && !stats;
+  const int rc = render_enqueue(c, s, host_out, dev_out, user_stream, no_alloc, bare);
+  if (rc != RTX_OK || bare) return rc;
+  return render_collect(c, stats);
 }
 
 // Render of a multi-device context.  The caller's shard (rows y with y % shard_count == shard_index, packed bottom-up: packed
 // row j is y = shard_index + shard_count * j) is dealt to the devices row by row: device k renders the packed rows j with
 // j % n == k, which is shard rtx_multi_shard(k) of the film, with the kernels and sample streams of a single-device render, so the
-// gathered film equals the single-device film bit for bit.  Each device renders on a host thread of its own into its own buffer;
-// the rows then go to the caller's film interleaved: to host memory by one strided copy per device (every device over its own
-// host link), to device memory by a copy to the first device followed by a strided copy there.
+// gathered film equals the single-device film bit for bit.
+// Every other device's share runs on that device's own host thread (kept since rtx_create_multi), the first device's on the
+// caller's.  A share is: enqueue the kernels on the device's stream; say so; then wait for them and read the statistics.  As soon
+// as a device has said so, its rows are ordered behind its render and sent on their way: to host memory by one strided copy per
+// device (issued by its own thread on its own stream: every device over its own host link), to device memory by a copy to a
+// staging buffer on the first device (a peer copy behind an event of the rendering stream, or ncclSend / ncclRecv) followed by a
+// strided copy there - all on the gather stream, which is waited for once, at the end.
 static int render_multi(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, rtx_stats* stats) {
   if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
   if (s->width <= 0 || s->height <= 0) return fail(RTX_ERR_INVALID_ARGUMENT, "bad settings: %dx%d", s->width, s->height);
@@ -677,55 +851,121 @@ static int render_multi(rtx_ctx* c, const rtx_settings* s, float* host_out, void
     if (rc != RTX_OK) return rc;
     rows[k] = rtx_shard_rows(s->height, sk[k].shard_index, sk[k].shard_count);
   }
-  std::vector<int> rcs(n, RTX_OK);
-  std::vector<std::string> errs(n);
-  std::vector<rtx_stats> sts(n);
-  auto one = [&](int k) {
-    rtx_ctx* x = all[k];
-    memset(&sts[k], 0, sizeof(rtx_stats));
-    if (rows[k] == 0) return;
-    try {
-      if (hipSetDevice(x->device) != hipSuccess) { rcs[k] = RTX_ERR_HIP; errs[k] = "hipSetDevice failed"; return; }
-      if (!x->film.ensure((size_t)rows[k] * row_bytes)) { rcs[k] = RTX_ERR_OUT_OF_MEMORY; errs[k] = "film buffer"; return; }
-      rcs[k] = render_impl(x, &sk[k], nullptr, x->film.ptr, nullptr, &sts[k]);   // returns with the device's rows complete
-      if (rcs[k] != RTX_OK) { errs[k] = g_error; return; }
-      if (host_out) {
-        const hipError_t e = hipMemcpy2D((char*)host_out + (size_t)k * row_bytes, (size_t)n * row_bytes, x->film.ptr, row_bytes, row_bytes, (size_t)rows[k], hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { rcs[k] = RTX_ERR_HIP; errs[k] = std::string("film copy to the host: ") + hipGetErrorString(e); }
-      }
-    } catch (const std::bad_alloc&) { rcs[k] = RTX_ERR_OUT_OF_MEMORY; errs[k] = "host allocation failed";
-    } catch (const std::exception& e) { rcs[k] = RTX_ERR_HIP; errs[k] = e.what(); }
+  struct Share {
+    int rc = RTX_OK;
+    std::string err;
+    rtx_stats st;
+    std::mutex m;
+    std::condition_variable cv;
+    bool enqueued = false;   // the share's kernels are on its stream (or it failed before that)
   };
-  std::vector<std::thread> th;
-  for (int k = 1; k < n; ++k) th.emplace_back(one, k);
-  one(0);
-  for (std::thread& t : th) t.join();
-  HIP_TRY(hipSetDevice(c->device));
-  for (int k = 0; k < n; ++k)
-    if (rcs[k] != RTX_OK) return fail(rcs[k], "render (device %d, shard %d of %d): %s", all[k]->device, sk[k].shard_index, sk[k].shard_count, errs[k].c_str());
-  if (dev_out) {
-    hipStream_t stream = user_stream ? user_stream : c->stream;
+  std::unique_ptr<Share[]> sh(new Share[n]);
+  for (int k = 0; k < n; ++k) memset(&sh[k].st, 0, sizeof(rtx_stats));
+  auto announce = [&](int k) {
+    { std::lock_guard<std::mutex> l(sh[k].m); sh[k].enqueued = true; }
+    sh[k].cv.notify_all();
+  };
+  auto enqueue_share = [&](int k) {   // -> the share's kernels are on all[k]->stream
+    rtx_ctx* x = all[k];
+    if (rows[k] == 0) return;
+    if (hipSetDevice(x->device) != hipSuccess) { sh[k].rc = RTX_ERR_HIP; sh[k].err = "hipSetDevice failed"; return; }
+    if (!x->film.ensure((size_t)rows[k] * row_bytes)) { sh[k].rc = RTX_ERR_OUT_OF_MEMORY; sh[k].err = "film buffer"; return; }
+    sh[k].rc = render_enqueue(x, &sk[k], nullptr, x->film.ptr, nullptr);
+    if (sh[k].rc != RTX_OK) { sh[k].err = g_error; return; }
+    if (host_out) {
+      const hipError_t e = hipMemcpy2DAsync((char*)host_out + (size_t)k * row_bytes, (size_t)n * row_bytes, x->film.ptr, row_bytes, row_bytes, (size_t)rows[k], hipMemcpyDeviceToHost, x->stream);
+      if (e != hipSuccess) { sh[k].rc = RTX_ERR_HIP; sh[k].err = std::string("film copy to the host: ") + hipGetErrorString(e); }
+    }
+  };
+  auto finish_share = [&](int k) {    // -> its kernels (and its copy to the host) are done, its statistics read
+    if (rows[k] == 0 || !all[k]->pending.active) return;
+    const int rc = render_collect(all[k], &sh[k].st);
+    if (rc != RTX_OK && sh[k].rc == RTX_OK) { sh[k].rc = rc; sh[k].err = g_error; }
+  };
+  auto guarded_part = [&](int k, auto&& part) {
+    try { part(k);
+    } catch (const std::bad_alloc&) { sh[k].rc = RTX_ERR_OUT_OF_MEMORY; sh[k].err = "host allocation failed";
+    } catch (const std::exception& e) { sh[k].rc = RTX_ERR_HIP; sh[k].err = e.what(); }
+  };
+  for (int k = 1; k < n; ++k)
+    c->workers[(size_t)k - 1]->post([&, k] {
+      guarded_part(k, enqueue_share);
+      announce(k);
+      guarded_part(k, finish_share);
+    });
+  guarded_part(0, enqueue_share);
+  announce(0);
+  // the gather into device memory, issued from this thread as the devices report in
+  int gather_rc = RTX_OK;
+  std::string gather_err;
+  hipStream_t gstream = user_stream ? user_stream : c->stream;
+  auto gather = [&]() -> int {
     size_t peer_bytes = 0;
     for (int k = 1; k < n; ++k) peer_bytes += (size_t)rows[k] * row_bytes;
+    HIP_TRY(hipSetDevice(c->device));
     if (peer_bytes && !c->gather.ensure(peer_bytes)) return fail(RTX_ERR_OUT_OF_MEMORY, "gather buffer (%zu bytes)", peer_bytes);
+    const bool rccl = c->gather_mode == RTX_GATHER_RCCL && n > 1 && (int)c->comms.size() == n;
+    const Rccl* R = rccl ? load_rccl(nullptr) : nullptr;
+    std::vector<void*> stage(n, nullptr);
     size_t at = 0;
+    for (int k = 1; k < n; ++k) { stage[k] = (char*)c->gather.ptr + at; at += (size_t)rows[k] * row_bytes; }
+    for (int k = 0; k < n; ++k) {   // every device's kernels must be on its stream before anything is ordered behind them
+      std::unique_lock<std::mutex> l(sh[k].m);
+      sh[k].cv.wait(l, [&] { return sh[k].enqueued; });
+      if (sh[k].rc != RTX_OK) return RTX_OK;   // reported below, with the share's own message
+    }
+    if (R) {
+      int e = R->GroupStart();
+      for (int k = 1; k < n && e == 0; ++k) {
+        if (rows[k] == 0) continue;
+        HIP_TRY(hipSetDevice(all[k]->device));
+        e = R->Send(all[k]->film.ptr, (size_t)rows[k] * (size_t)s->width * 3, Rccl::kFloat, 0, c->comms[(size_t)k], all[k]->stream);   // behind the render, in stream order
+      }
+      HIP_TRY(hipSetDevice(c->device));
+      if (e == 0 && gstream != c->stream) {   // the receives are ordered behind nothing of this device; its own rows are copied below
+        HIP_TRY(hipStreamWaitEvent(gstream, c->ev1, 0));
+      }
+      for (int k = 1; k < n && e == 0; ++k)
+        if (rows[k]) e = R->Recv(stage[k], (size_t)rows[k] * (size_t)s->width * 3, Rccl::kFloat, k, c->comms[0], gstream);
+      const int e2 = R->GroupEnd();
+      if (e != 0 || e2 != 0) return fail(RTX_ERR_HIP, "RCCL film gather: %s", R->GetErrorString(e != 0 ? e : e2));
+    }
     for (int k = 0; k < n; ++k) {
       if (rows[k] == 0) continue;
       const void* src = all[k]->film.ptr;
       if (k > 0) {
-        void* stage = (char*)c->gather.ptr + at;
-        at += (size_t)rows[k] * row_bytes;
-        HIP_TRY(hipMemcpyPeerAsync(stage, c->device, src, all[k]->device, (size_t)rows[k] * row_bytes, stream));
-        src = stage;
+        if (!R) {
+          HIP_TRY(hipStreamWaitEvent(gstream, all[k]->ev1, 0));   // recorded behind device k's kernels
+          HIP_TRY(hipMemcpyPeerAsync(stage[k], c->device, src, all[k]->device, (size_t)rows[k] * row_bytes, gstream));
+        }
+        src = stage[k];
+      } else if (gstream != c->stream && !R) {
+        HIP_TRY(hipStreamWaitEvent(gstream, c->ev1, 0));
       }
-      HIP_TRY(hipMemcpy2DAsync((char*)dev_out + (size_t)k * row_bytes, (size_t)n * row_bytes, src, row_bytes, row_bytes, (size_t)rows[k], hipMemcpyDeviceToDevice, stream));
+      HIP_TRY(hipMemcpy2DAsync((char*)dev_out + (size_t)k * row_bytes, (size_t)n * row_bytes, src, row_bytes, row_bytes, (size_t)rows[k], hipMemcpyDeviceToDevice, gstream));
     }
-    HIP_TRY(hipStreamSynchronize(stream));
+    return RTX_OK;
+  };
+  if (dev_out) {
+    try { gather_rc = gather();
+    } catch (const std::bad_alloc&) { gather_rc = fail(RTX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    } catch (const std::exception& e) { gather_rc = fail(RTX_ERR_HIP, "internal error: %s", e.what()); }
+    if (gather_rc != RTX_OK) gather_err = g_error;
   }
+  guarded_part(0, finish_share);
+  for (int k = 1; k < n; ++k) c->workers[(size_t)k - 1]->wait();   // nothing below may run while a worker still uses this frame
+  (void)hipSetDevice(c->device);
+  if (dev_out) {
+    const hipError_t e = hipStreamSynchronize(gstream);
+    if (e != hipSuccess && gather_rc == RTX_OK) { gather_rc = RTX_ERR_HIP; gather_err = std::string("film gather: ") + hipGetErrorString(e); }
+  }
+  for (int k = 0; k < n; ++k)
+    if (sh[k].rc != RTX_OK) return fail(sh[k].rc, "render (device %d, shard %d of %d): %s", all[k]->device, sk[k].shard_index, sk[k].shard_count, sh[k].err.c_str());
+  if (gather_rc != RTX_OK) return fail(gather_rc, "%s", gather_err.c_str());
   if (stats) {
-    rtx_stats t = sts[0];
+    rtx_stats t = sh[0].st;
     for (int k = 1; k < n; ++k) {
-      const rtx_stats& a = sts[k];
+      const rtx_stats& a = sh[k].st;
       t.samples += a.samples; t.rays_closest += a.rays_closest; t.rays_shadow += a.rays_shadow; t.segments += a.segments;
       t.nodes_visited += a.nodes_visited; t.prims_tested += a.prims_tested; t.kernel_launches += a.kernel_launches;
       // the devices run side by side: the call takes as long as the slowest
@@ -736,6 +976,31 @@ static int render_multi(rtx_ctx* c, const rtx_settings* s, float* host_out, void
     t.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
     *stats = t;
   }
+  return RTX_OK;
+}
+
+// RCCL for the film gather of a multi-device context: one communicator per device, created here.
+static int set_gather_impl(rtx_ctx* c, int mode) {
+  if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL context");
+  if (!c->multi) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_multi_set_gather takes a context made by rtx_create_multi");
+  if (mode != RTX_GATHER_PEER_COPY && mode != RTX_GATHER_RCCL) return fail(RTX_ERR_INVALID_ARGUMENT, "gather mode %d", mode);
+  if (mode == RTX_GATHER_PEER_COPY) { c->gather_mode = mode; return RTX_OK; }
+  std::vector<int> devs{c->device};
+  for (rtx_ctx* p : c->peers) devs.push_back(p->device);
+  for (size_t i = 0; i < devs.size(); ++i)
+    for (size_t j = i + 1; j < devs.size(); ++j)
+      if (devs[i] == devs[j]) return fail(RTX_ERR_UNSUPPORTED, "an RCCL communicator takes every device once: device %d is listed twice", devs[i]);
+  std::string why;
+  const Rccl* R = load_rccl(&why);
+  if (!R) return fail(RTX_ERR_UNSUPPORTED, "%s", why.c_str());
+  if (c->comms.empty()) {
+    std::vector<void*> comms(devs.size(), nullptr);
+    const int e = R->CommInitAll(comms.data(), (int)devs.size(), devs.data());
+    (void)hipSetDevice(c->device);
+    if (e != 0) return fail(RTX_ERR_HIP, "ncclCommInitAll over %zu devices: %s", devs.size(), R->GetErrorString(e));
+    c->comms = comms;
+  }
+  c->gather_mode = mode;
   return RTX_OK;
 }
 
@@ -756,6 +1021,20 @@ int rtx_render_device(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* 
   if (c && c->multi) return guarded([&] { return render_multi(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, stats); });
   return guarded([&] { return render_impl(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, stats); });
 }
+
+int rtx_render_device_async(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* hip_stream) {
+  if (!d_out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "d_out_rgb is NULL");
+  if (!hip_stream) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_device_async needs the caller's stream (hip_stream is NULL)");
+  if (c && c->multi) return fail(RTX_ERR_UNSUPPORTED, "the asynchronous render takes a single-device context (rtx_create)");
+  return guarded([&] { return render_enqueue(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream); });
+}
+
+int rtx_render_wait(rtx_ctx* c, rtx_stats* stats) {
+  if (c && c->multi) return fail(RTX_ERR_UNSUPPORTED, "the asynchronous render takes a single-device context (rtx_create)");
+  return guarded([&] { return render_collect(c, stats); });
+}
+
+int rtx_multi_set_gather(rtx_ctx* c, int mode) { return guarded([&] { return set_gather_impl(c, mode); }); }
 
 static int postprocess_impl(rtx_ctx* c, const float* h_film, const void* d_film, int width, int height, int mapper, double exposure, uint8_t* h_out,
                             void* d_out, hipStream_t user_stream) {
@@ -796,6 +1075,7 @@ static int trace_impl(rtx_ctx* c, const double* rays8, size_t n, rtx_hit* out, i
   if (!c || (!rays8 && n) || (!out && n)) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
   if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "trace before upload_scene");
   if (n == 0) return RTX_OK;
+  settle(c);
   static_assert(sizeof(DHitOut) == sizeof(rtx_hit), "hit layouts must agree");
   HIP_TRY(hipSetDevice(c->device));
   if (!c->rays.ensure(n * 8 * sizeof(double)) || !c->hits.ensure(n * sizeof(DHitOut))) return fail(RTX_ERR_OUT_OF_MEMORY, "ray batch of %zu", n);

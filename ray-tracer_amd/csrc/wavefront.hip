@@ -587,9 +587,9 @@ template <int MODE> void launch_turn_kernels(const DScene<float>& sc, const DCam
     launches += 2;
   }
   if (sorted) sort_queue(q_out, n_out, 0);
-  pool.mark(stream);
+  if (!pool.mark(stream)) pool.timing_ok = false;   // an event could not be made or recorded: this render reports no traversal time
   hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, n_out, stack_levels, counters, sorted ? A.order_out : A.q[q_out]);
-  pool.mark(stream);
+  if (!pool.mark(stream)) pool.timing_ok = false;
   ++launches;
 }
 
@@ -612,10 +612,21 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   if (items >= 0x7fffffffull) { err = "film too large for one launch"; return RTX_ERR_INVALID_ARGUMENT; }
   for (int count : {sc.n_spheres, sc.n_planes, sc.n_tris, sc.n_boxes, sc.n_quads, sc.n_disks})
     if (count > kIdMask) { err = "the queue pipeline indexes at most 2^28 primitives of one type"; return RTX_ERR_UNSUPPORTED; }
-  // Pool size: enough slots to keep every CU at full occupancy several times over.
-  const uint32_t n_slots = (uint32_t)std::min<unsigned long long>(items, (unsigned long long)n_cus * 2048ull * (unsigned long long)RTX_POOL_MULT);
-  if (!pool.state.ensure((size_t)kWfArrays * n_slots * 4) || !pool.control.ensure(sizeof(WfShared)) ||
-      !pool.queues.ensure((size_t)items * 3 * sizeof(float))) { err = "pool allocation"; return RTX_ERR_OUT_OF_MEMORY; }
+  // Pool size: enough slots to keep every work item in flight if memory allows (RTX_POOL_MULT slots per resident lane at most,
+  // kWfArrays * 4 bytes each: 5.4 GB for a 1080p frame at 64 spp).  A device that cannot give that much - shared, or holding a large
+  // scene - gets a pool of half the size, and so on down to 16 slots per lane (measured on the 10 M-triangle frame: 128: 721 ms, 32:
+  // 762, 16: 839); the environment variable RTX_POOL_MULT caps the first try.
+  if (!pool.control.ensure(sizeof(WfShared)) || !pool.queues.ensure((size_t)items * 3 * sizeof(float))) { err = "pool allocation (chunk sums)"; return RTX_ERR_OUT_OF_MEMORY; }
+  unsigned long long mult = (unsigned long long)RTX_POOL_MULT;
+  if (const char* e = getenv("RTX_POOL_MULT")) { const long v = atol(e); if (v >= 1 && (unsigned long long)v < mult) mult = (unsigned long long)v; }
+  uint32_t n_slots = 0;
+  for (;;) {
+    n_slots = (uint32_t)std::min<unsigned long long>(items, (unsigned long long)n_cus * 2048ull * mult);
+    if (pool.state.ensure((size_t)kWfArrays * n_slots * 4)) break;
+    (void)hipGetLastError();   // the failed allocation's error code
+    if (mult <= 16ull) { err = "pool allocation (" + std::to_string((size_t)kWfArrays * n_slots * 4) + " bytes of path slots, the smallest pool tried)"; return RTX_ERR_OUT_OF_MEMORY; }
+    mult /= 2ull;
+  }
   WfArrays A;
   {
     uint32_t* base = (uint32_t*)pool.state.ptr;
@@ -665,6 +676,7 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   };
   if (hipMemsetAsync(pool.control.ptr, 0, sizeof(WfShared), stream) != hipSuccess) { err = "memset"; return RTX_ERR_HIP; }
   pool.events_used = 0;
+  pool.timing_ok = true;
   unsigned live_bound = n_slots;   // upper bound of the ray queue length (it only shrinks)
   unsigned grid = (live_bound + kBlock - 1) / kBlock;
   run(nullptr, grid);

@@ -37,3 +37,46 @@ def gather_film(local: torch.Tensor, height: int, width: int, rank: int, world: 
         return full
     dist.gather(send, gather_list=None, dst=dst)
     return None
+
+
+class ShardedFilms:
+    """The shards of SEVERAL films (the scenes of one frame set) in ONE buffer per rank, so that a step makes one gather
+    whatever the number of scenes, with nothing allocated inside the step.
+
+    Every film's share is padded to the largest share (rows of rank 0), so all ranks send the same number of floats.
+    `local[i]` is this rank's packed [rows, W, 3] view for film i: render into it.  `gather()` sends the buffer to rank 0, which
+    receives into one [world, total] buffer and re-interleaves each film with one strided copy:
+    packed row j of rank k is film row k + world * j."""
+
+    def __init__(self, shapes, rank: int, world: int, device):
+        self.shapes, self.rank, self.world = [(int(h), int(w)) for h, w in shapes], rank, world
+        self.rmax = [shard_rows(h, 0, world) for h, _ in self.shapes]
+        sizes = [r * w * 3 for r, (_, w) in zip(self.rmax, self.shapes)]
+        self.offs = [sum(sizes[:i]) for i in range(len(sizes))]
+        self.total = sum(sizes)
+        self.send = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.local = []
+        for (h, w), off in zip(self.shapes, self.offs):
+            rows = shard_rows(h, rank, world)
+            self.local.append(self.send[off: off + rows * w * 3].view(rows, w, 3))
+        root = world > 1 and rank == 0
+        self.recv = torch.empty((world, self.total), dtype=torch.float32, device=device) if root else None
+        self.full = [torch.empty((r * world, w, 3), dtype=torch.float32, device=device) for r, (_, w) in zip(self.rmax, self.shapes)] if root else None
+
+    def bytes_into_root(self) -> int:
+        return (self.world - 1) * self.total * 4
+
+    def gather(self):
+        """-> the whole films [H, W, 3] on rank 0 (views of buffers this object keeps), None on the other ranks."""
+        if self.world == 1:
+            return list(self.local)
+        if self.rank != 0:
+            dist.gather(self.send, gather_list=None, dst=0)
+            return None
+        dist.gather(self.send, gather_list=list(self.recv.unbind(0)), dst=0)
+        films = []
+        for (h, w), off, r, full in zip(self.shapes, self.offs, self.rmax, self.full):
+            part = self.recv[:, off: off + r * w * 3].view(self.world, r, w, 3)
+            full.view(r, self.world, w, 3).copy_(part.permute(1, 0, 2, 3))
+            films.append(full[:h])
+        return films

@@ -92,6 +92,23 @@ class HipPathTracer:
         self.last_stats = stats
         return stats
 
+    def render_device_async(self, device_ptr: int, stream: int):
+        """rtx_render_device_async: enqueue the render on `stream` and return; `render_wait` collects it."""
+        st = self._settings
+        if st is None:
+            raise abi.RtxError("render before set_settings")
+        abi.check(self._lib, self._lib.rtx_render_device_async(self._ctx, C.byref(st), C.c_void_p(device_ptr), C.c_void_p(stream)), "rtx_render_device_async")
+
+    def render_wait(self) -> abi.Stats:
+        stats = abi.Stats()
+        abi.check(self._lib, self._lib.rtx_render_wait(self._ctx, C.byref(stats)), "rtx_render_wait")
+        self.last_stats = stats
+        return stats
+
+    def set_gather(self, mode: int):
+        """rtx_multi_set_gather: how a multi-device context gathers device-memory films (abi.GATHER_PEER_COPY / GATHER_RCCL)."""
+        abi.check(self._lib, self._lib.rtx_multi_set_gather(self._ctx, int(mode)), "rtx_multi_set_gather")
+
     def render_device_noalloc(self, device_ptr: int, stream: int = 0, want_stats: bool = True) -> abi.Stats | None:
         """rtx_render_device_noalloc: the same render without any device allocation (small films, fused pipeline)."""
         st = self._settings

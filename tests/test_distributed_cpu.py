@@ -58,3 +58,53 @@ def test_gather_film_world_one_is_identity(pkg):
     t = torch.arange(5 * 4 * 3, dtype=torch.float32).reshape(5, 4, 3)
     assert parallel.gather_film(t, 5, 4, 0, 1) is t
     assert [parallel.shard_rows(13, r, 4) for r in range(4)] == [4, 3, 3, 3]
+
+
+def _sharded_worker(rank, world, port, shapes, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import rtx_pkg
+    rtx_pkg.load()
+    import importlib
+    parallel = importlib.import_module("raytracer_amd.parallel")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        films = parallel.ShardedFilms(shapes, rank, world, "cpu")
+        for step in range(2):   # a second step reuses every buffer
+            for i, ((h, w), local) in enumerate(zip(shapes, films.local)):
+                whole = _pattern(h, w, i, step)
+                local.copy_(whole[rank::world])
+            full = films.gather()
+            if rank == 0:
+                assert [tuple(f.shape) for f in full] == [(h, w, 3) for h, w in shapes]
+                for i, f in enumerate(full):
+                    assert torch.equal(f, _pattern(*shapes[i], i, step)), (i, step)
+            else:
+                assert full is None
+        if rank == 0:
+            open(out_path, "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def _pattern(h, w, film, step):
+    return (torch.arange(h * w * 3, dtype=torch.float32).reshape(h, w, 3) + 1000.0 * film + 0.5 * step)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_films_gather_several_films_in_one_exchange(world, pkg, tmp_path):
+    shapes = [(12, 5), (13, 4), (2, 3)]   # equal shares, unequal shares, fewer rows than ranks (world 3)
+    out = str(tmp_path / "ok.txt")
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_sharded_worker, args=(world, port, shapes, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_sharded_films_world_one(pkg):
+    import importlib
+    parallel = importlib.import_module("raytracer_amd.parallel")
+    films = parallel.ShardedFilms([(4, 3), (5, 2)], 0, 1, "cpu")
+    films.local[1].fill_(2.0)
+    out = films.gather()
+    assert out[0].shape == (4, 3, 3) and out[1].shape == (5, 2, 3) and float(out[1].sum()) == 60.0
+    assert films.bytes_into_root() == 0
