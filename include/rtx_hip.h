@@ -160,6 +160,8 @@ typedef struct rtx_stats {
   double seconds_extend;     /* device time of its launches, summed (HIP events around each) */
   uint64_t nodes_visited;    /* node records it fetched and tested */
   uint64_t prims_tested;     /* leaf records it fetched and tested */
+  uint64_t nodes_visited_shadow; /* the same two counts for the any-hit traversal kernel of the shadow-ray queue */
+  uint64_t prims_tested_shadow;
 } rtx_stats;
 
 /* One closest-hit result: the members of hit_record (core/hit.h:20-29) that identify the

@@ -605,6 +605,7 @@ static int render_collect(rtx_ctx* c, rtx_stats* stats) {
   st.samples = hc.samples; st.rays_closest = hc.closest; st.rays_shadow = hc.shadow; st.segments = hc.segments;
   if (pd.photon_map_reused) st.rays_closest += c->ph_map.closest;   // the queries this film's photon map was traced with, made by an earlier call
   st.nodes_visited = hc.nodes_visited; st.prims_tested = hc.prims_tested;
+  st.nodes_visited_shadow = hc.nodes_visited_shadow; st.prims_tested_shadow = hc.prims_tested_shadow;
   if (pd.wavefront) st.seconds_extend = c->wf.timed_seconds();
   st.seconds_render = ms * 1e-3;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->evm));
@@ -968,6 +969,7 @@ static int render_multi(rtx_ctx* c, const rtx_settings* s, float* host_out, void
       const rtx_stats& a = sh[k].st;
       t.samples += a.samples; t.rays_closest += a.rays_closest; t.rays_shadow += a.rays_shadow; t.segments += a.segments;
       t.nodes_visited += a.nodes_visited; t.prims_tested += a.prims_tested; t.kernel_launches += a.kernel_launches;
+      t.nodes_visited_shadow += a.nodes_visited_shadow; t.prims_tested_shadow += a.prims_tested_shadow;
       // the devices run side by side: the call takes as long as the slowest
       t.seconds_render = std::max(t.seconds_render, a.seconds_render); t.seconds_main_kernel = std::max(t.seconds_main_kernel, a.seconds_main_kernel);
       t.seconds_photon_pass = std::max(t.seconds_photon_pass, a.seconds_photon_pass); t.seconds_extend = std::max(t.seconds_extend, a.seconds_extend);

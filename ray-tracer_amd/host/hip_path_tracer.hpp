@@ -46,6 +46,16 @@ class HipPathTracer {
   void postprocess(const float* film, int width, int height, int tone_mapper, double exposure, unsigned char* out_rgb8) {
     if (ctx_) note(rtx_postprocess(ctx_, film, width, height, tone_mapper, exposure, out_rgb8), "postprocess");
   }
+  // Additions of this backend: the film in device memory (of the first device), also in two halves (enqueue on the caller's
+  // stream, wait later), and the choice of the multi-device film gather (RTX_GATHER_PEER_COPY / RTX_GATHER_RCCL).
+  void render_device(void* d_output, void* hip_stream = nullptr) {
+    if (ready("render_device")) note(rtx_render_device(ctx_, &settings_, d_output, hip_stream, &stats_), "render_device");
+  }
+  void render_device_async(void* d_output, void* hip_stream) {
+    if (ready("render_device_async")) note(rtx_render_device_async(ctx_, &settings_, d_output, hip_stream), "render_device_async");
+  }
+  void render_wait() { if (ctx_) note(rtx_render_wait(ctx_, &stats_), "render_wait"); }
+  void set_gather(int mode) { if (ctx_) note(rtx_multi_set_gather(ctx_, mode), "set_gather"); }
   void trace_closest(const double* rays8, size_t n, rtx_hit* out) { if (ctx_) note(rtx_trace_closest(ctx_, rays8, n, out), "trace_closest"); }
 
   bool ok() const { return status_ == RTX_OK; }
@@ -53,6 +63,11 @@ class HipPathTracer {
   const rtx_stats& stats() const { return stats_; }
 
  private:
+  bool ready(const char* what) {
+    if (!ctx_) return false;
+    if (!have_settings_) { status_ = RTX_ERR_NOT_READY; std::fprintf(stderr, "HIP %s: set_settings was not called\n", what); return false; }
+    return true;
+  }
   void note(int rc, const char* what) {
     status_ = rc;
     if (rc != RTX_OK) std::fprintf(stderr, "HIP %s failed (%d): %s\n", what, rc, rtx_last_error());

@@ -1,0 +1,123 @@
+"""Additions of the C ABI that change HOW a render runs, never its result: the two-halves render (rtx_render_device_async /
+rtx_render_wait), the entry points of the queue pipeline's tree walks (rays that leave a primitive start a few levels above its
+leaf), the smaller pools the queue pipeline falls back to, and the RCCL film gather of a multi-device context.  Every film must
+equal the plain one bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import soup_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def test_async_render_equals_synchronous_render(pkg, load_scene):
+    import torch
+    abi = pkg.abi
+    stream = torch.cuda.current_stream().cuda_stream
+    cases = [(load_scene("cornell_box"), dict(width=160, height=90, samples_per_pixel=12, max_depth=10, seed=3)),
+             (soup_scene(pkg, load_scene), dict(width=80, height=45, samples_per_pixel=6, max_depth=8, seed=4))]   # fused, then the queue pipeline
+    tracers = []
+    for sd, kw in cases:
+        pt = pkg.renderer.HipPathTracer(0)
+        pt.upload_scene(sd)
+        pt.set_camera(sd.camera(kw["width"], kw["height"]))
+        pt.set_settings(sd.settings(**kw))
+        tracers.append(pt)
+    want, ref_stats = [], []
+    for pt, (sd, kw) in zip(tracers, cases):
+        t = torch.zeros((kw["height"], kw["width"], 3), dtype=torch.float32, device="cuda:0")
+        ref_stats.append(pt.render_device(t.data_ptr(), stream))
+        want.append(t)
+    for _ in range(2):
+        got = [torch.full_like(w, -1.0) for w in want]
+        for pt, g in zip(tracers, got):          # both renders are enqueued before either is waited for
+            pt.render_device_async(g.data_ptr(), stream)
+        stats = [pt.render_wait() for pt in tracers]
+        for g, w, s, r in zip(got, want, stats, ref_stats):
+            assert np.array_equal(_bits(g), _bits(w))
+            assert (s.samples, s.rays_closest, s.rays_shadow, s.segments) == (r.samples, r.rays_closest, r.rays_shadow, r.segments)
+            assert s.seconds_render > 0 and s.seconds_total >= s.seconds_render * 0.5
+    # a render that was never collected is waited for by the next call on the context; waiting twice is an error
+    pt = tracers[0]
+    g = torch.full_like(want[0], -1.0)
+    pt.render_device_async(g.data_ptr(), stream)
+    again = torch.full_like(want[0], -1.0)
+    pt.render_device(again.data_ptr(), stream)
+    assert np.array_equal(_bits(g), _bits(want[0])) and np.array_equal(_bits(again), _bits(want[0]))
+    with pytest.raises(abi.RtxError, match="no render in flight"):
+        pt.render_wait()
+    lib = abi.load_library()
+    assert lib.rtx_render_device_async(pt._ctx, None, None, None) == -1
+    for pt in tracers:
+        pt.close()
+
+
+def _queue_film(pkg, sd, env, **kw):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        with pkg.renderer.HipPathTracer(0) as pt:
+            pt.upload_scene(sd)                      # RTX_ENTRY_LEVELS is read here, RTX_POOL_MULT at the render
+            pt.set_camera(sd.camera(kw["width"], kw["height"]))
+            pt.set_settings(sd.settings(pipeline=pkg.abi.PIPELINE_WAVEFRONT, **kw))
+            film = pt.render().copy()
+            return film, pt.last_stats
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_entry_points_change_the_work_not_the_film(pkg, load_scene):
+    sd = soup_scene(pkg, load_scene, n=60000)
+    kw = dict(width=120, height=68, samples_per_pixel=8, max_depth=8, seed=21)
+    base, st0 = _queue_film(pkg, sd, {"RTX_ENTRY_LEVELS": "0"}, **kw)    # every walk starts at the root
+    assert st0.nodes_visited > 0 and st0.nodes_visited_shadow > 0
+    for levels in ("1", "2", "3", "5", "16"):
+        film, st = _queue_film(pkg, sd, {"RTX_ENTRY_LEVELS": levels}, **kw)
+        assert np.array_equal(film.view(np.uint32), base.view(np.uint32)), levels
+        assert (st.samples, st.rays_closest, st.rays_shadow, st.segments) == (st0.samples, st0.rays_closest, st0.rays_shadow, st0.segments)
+    # a tenth of the pool: slots are reused more often, the film is the same
+    film, _ = _queue_film(pkg, sd, {"RTX_POOL_MULT": "1"}, width=640, height=360, samples_per_pixel=16, max_depth=6, seed=2)
+    want, _ = _queue_film(pkg, sd, {}, width=640, height=360, samples_per_pixel=16, max_depth=6, seed=2)
+    assert np.array_equal(film.view(np.uint32), want.view(np.uint32))
+
+
+def test_rccl_gather_of_a_multi_device_context(pkg, load_scene):
+    import torch
+    abi = pkg.abi
+    sd = load_scene("cornell_box")
+    kw = dict(width=96, height=54, samples_per_pixel=8, max_depth=6, seed=11)
+    with pkg.renderer.HipPathTracer(0) as one:
+        one.upload_scene(sd)
+        one.set_camera(sd.camera(96, 54))
+        one.set_settings(sd.settings(**kw))
+        whole = one.render().copy()
+        with pytest.raises(abi.RtxError, match="rtx_create_multi"):
+            one.set_gather(abi.GATHER_RCCL)
+    with pkg.renderer.HipPathTracer(device_ids=[0]) as multi:   # one device: the communicator is made, nothing needs to be sent
+        multi.set_gather(abi.GATHER_RCCL)
+        multi.upload_scene(sd)
+        multi.set_camera(sd.camera(96, 54))
+        multi.set_settings(sd.settings(**kw))
+        out = torch.full(whole.shape, -1.0, dtype=torch.float32, device="cuda:0")
+        multi.render_device(out.data_ptr())
+        assert np.array_equal(out.cpu().numpy(), whole)
+        multi.set_gather(abi.GATHER_PEER_COPY)
+        with pytest.raises(abi.RtxError, match="gather mode"):
+            multi.set_gather(7)
+    with pkg.renderer.HipPathTracer(device_ids=[0, 0]) as twice:
+        with pytest.raises(abi.RtxError, match="listed twice"):
+            twice.set_gather(abi.GATHER_RCCL)
+        twice.upload_scene(sd)                                    # the context still works with peer copies
+        twice.set_camera(sd.camera(96, 54))
+        twice.set_settings(sd.settings(**kw))
+        assert np.array_equal(twice.render(), whole)
