@@ -160,8 +160,6 @@ typedef struct rtx_stats {
   double seconds_extend;     /* device time of its launches, summed (HIP events around each) */
   uint64_t nodes_visited;    /* node records it fetched and tested */
   uint64_t prims_tested;     /* leaf records it fetched and tested */
-  uint64_t nodes_visited_shadow; /* the same two counts for the any-hit traversal kernel of the shadow-ray queue */
-  uint64_t prims_tested_shadow;
 } rtx_stats;
 
 /* One closest-hit result: the members of hit_record (core/hit.h:20-29) that identify the
@@ -232,8 +230,9 @@ int rtx_render_device(rtx_ctx* ctx, const rtx_settings* settings, void* d_out_rg
 
 /* rtx_render_device in two halves, for callers that want the host back while the GPU renders (a second scene on another context,
  * a film gather of the previous frame).  It has no counterpart in the reference, whose GPUPathTracer::render is synchronous
- * (cuda_pathtracer.cu:375).  rtx_render_device_async puts the render on `hip_stream` (not NULL: the caller must be able to order
- * its own work behind it) and returns without waiting; the film is complete where the stream stands at that moment.  The fused
+ * (cuda_pathtracer.cu:375).  rtx_render_device_async puts the render on `hip_stream` - the caller's stream, taken as given: NULL
+ * is HIP's default stream here, not the context's own, so that the caller can order its work behind the render - and
+ * returns without waiting; the film is complete where the stream stands at that moment.  The fused
  * pipeline enqueues and returns at once; the queue-based pipeline reads its queue lengths back between kernels, so the call
  * returns when its last kernels are enqueued.  rtx_render_wait waits for that render and fills `stats` (may be NULL).  A context
  * holds ONE render in flight: any other render call on it first waits for the one pending.  Single-device contexts only. */

@@ -90,8 +90,7 @@ class Stats(C.Structure):
                 ("segments", C.c_uint64), ("seconds_render", C.c_double), ("seconds_main_kernel", C.c_double), ("seconds_total", C.c_double),
                 ("kernel_launches", C.c_uint32), ("pipeline_used", C.c_uint32),
                 ("precision_used", C.c_uint32), ("reserved_", C.c_uint32), ("seconds_photon_pass", C.c_double),
-                ("seconds_extend", C.c_double), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
-                ("nodes_visited_shadow", C.c_uint64), ("prims_tested_shadow", C.c_uint64)]
+                ("seconds_extend", C.c_double), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64)]
 
 
 class Hit(C.Structure):

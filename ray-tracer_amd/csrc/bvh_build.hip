@@ -132,7 +132,7 @@ __device__ __forceinline__ int find_split(const uint64_t* __restrict__ codes, in
 }
 
 __global__ __launch_bounds__(256) void split_level_kernel(const uint64_t* __restrict__ codes, int2* range, NodeMeta* __restrict__ meta, int2* __restrict__ leaf_range,
-                                                          int32_t* __restrict__ unit_of, int32_t* __restrict__ parent_of, int first, int count, BuildCounters* ctr) {
+                                                          int32_t* __restrict__ unit_of, int first, int count, BuildCounters* ctr) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count) return;
   const int node = first + t;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void split_level_kernel(const uint64_t* __rest
   const int ub = (int)atomicAdd(&ctr->units, (uint32_t)n);
   int ki = 0, kl = 0;
   for (int i = 0; i < n; ++i) {
-    if (re[i] - rb[i] > kLeafMaxPrims) { unit_of[ib + ki] = ub + ki; parent_of[ib + ki] = node; range[ib + ki++] = make_int2(rb[i], re[i]); }
+    if (re[i] - rb[i] > kLeafMaxPrims) { unit_of[ib + ki] = ub + ki; range[ib + ki++] = make_int2(rb[i], re[i]); }
     else leaf_range[lb + kl++] = make_int2(rb[i], re[i] - rb[i]);
   }
   NodeMeta m;
@@ -171,7 +171,6 @@ __global__ __launch_bounds__(256) void split_level_kernel(const uint64_t* __rest
 __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, const NodeMeta* __restrict__ meta, const int2* __restrict__ leaf_range,
                                                          const uint32_t* __restrict__ order, const float4* __restrict__ plo, const float4* __restrict__ phi,
                                                          float4* nlo, float4* nhi, DNode8* __restrict__ units, const int32_t* __restrict__ unit_of,
-                                                         const int32_t* __restrict__ parent_of, int entry_levels,
                                                          const DTri<float>* __restrict__ tris, int ns, int nt, OriginGrid grid) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = g & 7;
@@ -189,11 +188,7 @@ __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, c
       DLeaf rec;
       for (int j = 0; j < 9; ++j) rec.v[j] = NAN;
       rec.ref = -1;
-      // the node `entry_levels` above the leaf (its parent is one level above; the root is its own parent)
-      int up = node;
-      for (int j = 1; j < entry_levels; ++j) up = parent_of[up];
-      rec.entry = entry_levels > 0 ? unit_of[up] : 0;
-      for (int j = 0; j < 5; ++j) rec.pad[j] = 0;
+      for (int j = 0; j < 6; ++j) rec.pad[j] = 0;
       if (lr.y > 0) {
         const int p = (int)order[lr.x];
         const float4 a = plo[p], b = phi[p];
@@ -274,7 +269,7 @@ struct Temp {
     if (e_ != hipSuccess) { err = std::string(#expr ": ") + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? RTX_ERR_OUT_OF_MEMORY : RTX_ERR_HIP; } \
   } while (0)
 
-int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, int entry_levels, WideTree& out, std::string& err) {
+int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& out, std::string& err) {
   const auto t0 = std::chrono::steady_clock::now();
   const int ns = sc.n_spheres, nt = sc.n_tris, nb = sc.n_boxes;
   const int n = ns + nt + nb;
@@ -282,10 +277,10 @@ int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, int entry_le
   if (n <= 0) return RTX_OK;
   hipStream_t stream = nullptr;
   const unsigned grid = (unsigned)((n + 255) / 256);
-  Temp lo4, hi4, codes_a, codes_b, ids_a, ids_b, range, meta, leaf_range, unit_of, parent_of, ctr, sort_tmp, nlo, nhi;
+  Temp lo4, hi4, codes_a, codes_b, ids_a, ids_b, range, meta, leaf_range, unit_of, ctr, sort_tmp, nlo, nhi;
   if (!lo4.alloc((size_t)n * 16) || !hi4.alloc((size_t)n * 16) || !codes_a.alloc((size_t)n * 8) || !codes_b.alloc((size_t)n * 8) || !ids_a.alloc((size_t)n * 4) ||
       !ids_b.alloc((size_t)n * 4) || !range.alloc((size_t)n * 8) || !meta.alloc((size_t)n * sizeof(NodeMeta)) || !leaf_range.alloc((size_t)n * 8) ||
-      !unit_of.alloc((size_t)n * 4) || !parent_of.alloc((size_t)n * 4) || !ctr.alloc(sizeof(BuildCounters))) { err = "tree build: temporary buffers"; return RTX_ERR_OUT_OF_MEMORY; }
+      !unit_of.alloc((size_t)n * 4) || !ctr.alloc(sizeof(BuildCounters))) { err = "tree build: temporary buffers"; return RTX_ERR_OUT_OF_MEMORY; }
   BuildCounters hc;
   hc.nodes = 1u; hc.leaves = 0u; hc.units = 2u;   // the root's record is unit 0; unit 1 pads to an even start
   for (int a = 0; a < 3; ++a) { hc.cmin[a] = 0xffffffffu; hc.cmax[a] = 0u; hc.bmin[a] = 0xffffffffu; hc.bmax[a] = 0u; }
@@ -304,12 +299,11 @@ int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, int entry_le
   const int2 root = make_int2(0, n);
   BUILD_TRY(hipMemcpyAsync(range.p, &root, sizeof root, hipMemcpyHostToDevice, stream));
   BUILD_TRY(hipMemsetAsync(unit_of.p, 0, 4, stream));
-  BUILD_TRY(hipMemsetAsync(parent_of.p, 0, 4, stream));   // the root is its own parent
   std::vector<int> level_first{0};
   int first = 0, count = 1;
   while (count > 0) {
     hipLaunchKernelGGL(split_level_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, codes, range.as<int2>(), meta.as<NodeMeta>(),
-                       leaf_range.as<int2>(), unit_of.as<int32_t>(), parent_of.as<int32_t>(), first, count, ctr.as<BuildCounters>());
+                       leaf_range.as<int2>(), unit_of.as<int32_t>(), first, count, ctr.as<BuildCounters>());
     BUILD_TRY(hipMemcpyAsync(&hc, ctr.p, sizeof hc, hipMemcpyDeviceToHost, stream));
     BUILD_TRY(hipStreamSynchronize(stream));
     first += count;
@@ -338,8 +332,7 @@ int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, int entry_le
   for (int L = levels - 1; L >= 0; --L) {
     const int f = level_first[(size_t)L], c = level_first[(size_t)L + 1] - f;
     hipLaunchKernelGGL(emit_level_kernel, dim3((unsigned)(((size_t)c * 8 + 255) / 256)), dim3(256), 0, stream, f, c, meta.as<NodeMeta>(), leaf_range.as<int2>(), order,
-                       lo4.as<float4>(), hi4.as<float4>(), nlo.as<float4>(), nhi.as<float4>(), (DNode8*)out.nodes.ptr, unit_of.as<int32_t>(), parent_of.as<int32_t>(),
-                       entry_levels, sc.tris, ns, nt, og);
+                       lo4.as<float4>(), hi4.as<float4>(), nlo.as<float4>(), nhi.as<float4>(), (DNode8*)out.nodes.ptr, unit_of.as<int32_t>(), sc.tris, ns, nt, og);
   }
   BUILD_TRY(hipGetLastError());
   float4 root_lo, root_hi;

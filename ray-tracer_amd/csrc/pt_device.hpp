@@ -316,7 +316,8 @@ template <class R, bool WANT_UV> RTX_DEV void finalize_hit(const DScene<R>& sc, 
 // Per-lane traversal stack in LDS, laid out [level][lane] so a wave's accesses to one level
 // are one conflict-free row.
 struct LaneStack {
-  int* base; int stride;   // word i of this lane's stack is base[i * stride]
+  int* base;
+  static constexpr int stride = kBlock;   // word i of this lane's stack is base[i * stride]: every kernel with stacks runs kBlock-lane workgroups (a constant keeps a multiply out of every push and pop)
   RTX_DEV int& at(int level) const { return base[level * stride]; }
   RTX_DEV void push(int& sp, int v) const { base[sp * stride] = v; ++sp; }
   RTX_DEV int pop(int& sp) const { --sp; return base[sp * stride]; }
@@ -403,14 +404,13 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
 // its primitives.  On an exact tie in t the primitive later in the reference's leaf order wins, whatever the visiting order
 // (DScene::rank; best_p = the current winner's primitive number).
 // ------------------------------------------------------------------------------------------
-// best_anc: the entry point the winner's leaf record names (DLeaf::entry), 0 (the root) while there is no winner.
-struct Walk8 { V3<float> inv; int node, sp, best_p, best_anc; };
+struct Walk8 { V3<float> inv; int node, sp, best_p; };
 
 RTX_DEV void walk8_begin(Walk8& w, const Ray<float>& r) {
   // the quantised boxes multiply 1/d by box units: keep it finite (a direction component below 1e-18 moves the ray by less
   // than 1e-9 over the longest ray, so the slab of that axis is constant along it either way)
   w.inv = {fminf(fmaxf(1.0f / r.d.x, -1e18f), 1e18f), fminf(fmaxf(1.0f / r.d.y, -1e18f), 1e18f), fminf(fmaxf(1.0f / r.d.z, -1e18f), 1e18f)};
-  w.node = 0; w.sp = 0; w.best_p = -1; w.best_anc = 0;
+  w.node = 0; w.sp = 0; w.best_p = -1;
 }
 RTX_DEV bool walk8_at_inner(const Walk8& w) { return w.node >= 0 && w.node != kWalkDone; }
 RTX_DEV bool walk8_at_leaf(const Walk8& w) { return w.node < 0; }
@@ -532,7 +532,8 @@ RTX_DEV bool leaf_tri_t(const float* v, const Ray<float>& r, float t_min, float 
 // Tests the primitive of the leaf record with code `leaf` (a ~unit) against the ray; updates the candidate and the tie state.
 RTX_DEV void walk8_leaf_test(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, Walk8& w, int leaf) {
   const uint4* rec = reinterpret_cast<const uint4*>(sc.nodes8 + (~leaf));
-  const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];   // vertices, ref, entry
+  const uint4 q0 = rec[0], q1 = rec[1];
+  const uint2 q2 = *reinterpret_cast<const uint2*>(rec + 2);
   const float v[9] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w), __uint_as_float(q1.x),
                       __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
   const int ref = (int)q2.y;
@@ -540,7 +541,7 @@ RTX_DEV void walk8_leaf_test(const DScene<float>& sc, const Ray<float>& r, float
   // (the range check on ref costs two instructions and keeps a record that is no leaf record from ever being taken for a triangle)
   bool ok = leaf_tri_t(v, r, t_min, c.t, t, u, vv) && (uint32_t)(ref - sc.n_spheres) < (uint32_t)sc.n_tris;
   if (ok && t == c.t && w.best_p >= 0) ok = sc.rank[ref] > sc.rank[w.best_p];   // exact tie: the later one in the reference's order wins
-  if (ok) { c.t = t; c.type = PRIM_TRIANGLE; c.idx = ref - sc.n_spheres; c.uv_kind = 1; c.ua = u; c.ub = vv; w.best_p = ref; w.best_anc = (int)q2.z; }
+  if (ok) { c.t = t; c.type = PRIM_TRIANGLE; c.idx = ref - sc.n_spheres; c.uv_kind = 1; c.ua = u; c.ub = vv; w.best_p = ref; }
   const int p = -2 - ref;
   const bool sphere = (uint32_t)p < (uint32_t)sc.n_spheres, box = (uint32_t)(p - sc.n_spheres - sc.n_tris) < (uint32_t)sc.n_boxes;
   if (ref < -1 && (sphere || box)) {   // rare in a tree of triangles
@@ -549,7 +550,7 @@ RTX_DEV void walk8_leaf_test(const DScene<float>& sc, const Ray<float>& r, float
     Cand<float> trial = c;
     test_bounded(sc, type, idx, r, t_min, trial);
     const bool changed = trial.type == type && trial.idx == idx && (trial.t != c.t || c.type != type || c.idx != idx);
-    if (changed && !(trial.t == c.t && w.best_p >= 0 && sc.rank[p] < sc.rank[w.best_p])) { c = trial; w.best_p = p; w.best_anc = (int)q2.z; }
+    if (changed && !(trial.t == c.t && w.best_p >= 0 && sc.rank[p] < sc.rank[w.best_p])) { c = trial; w.best_p = p; }
   }
 }
 

@@ -483,11 +483,7 @@ int HostScene::upload_tree(const rtx_scene_desc& d, const ScenePrep& prep, std::
     lap("ranks and unreachable primitives");
     if (ok) {
       std::string berr;
-      // Entry points of rays that start on a primitive (wavefront.hip): measured on the 10 M-triangle soup, see kEntryLevels.
-      int entry_levels = kEntryLevels;
-      if (const char* e = getenv("RTX_ENTRY_LEVELS")) { const int v = atoi(e); if (v >= 0 && v <= 16) entry_levels = v; }   // experiments
-      dev_f.entry_levels = entry_levels;
-      const int rc = build_wide_tree(dev_f, d_dead, entry_levels, wide, berr);
+      const int rc = build_wide_tree(dev_f, d_dead, wide, berr);
       if (rc != RTX_OK) { release(); err = berr; return rc; }
       if (wide.levels > kMaxWalkLevels) {
         err = "the traversal tree of this scene is " + std::to_string(wide.levels) + " levels deep (at most " + std::to_string(kMaxWalkLevels) + " are walked)";

@@ -53,8 +53,7 @@ struct WideTree {
 };
 // `sc`: the single-precision scene with its primitive tables already on the device; `d_dead`: optional device array, one byte per
 // bounded primitive (numbered spheres, triangles, boxes), non-zero = the reference can never hit it (built in as unhittable).
-// entry_levels: how many levels above its leaf a primitive's entry point lies (DLeaf::entry; 0 = always the root).
-int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, int entry_levels, WideTree& out, std::string& err);
+int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& out, std::string& err);
 
 // What an upload derives from the description on the host alone: computed once, shared by every device that receives the scene.
 struct ScenePrep {

@@ -12,7 +12,6 @@ extern __shared__ int lds_dyn[];
 RTX_DEV LaneStack lane_stack(int first_int) {
   LaneStack st;
   st.base = lds_dyn + first_int + threadIdx.x;
-  st.stride = blockDim.x;
   return st;
 }
 

@@ -57,21 +57,13 @@ constexpr int kNodeOriginBits = 21;
 // the reference's primitive list (spheres, then triangles, then boxes: engine/scene.hpp:496-533); ref == -1: nothing to test (a
 // primitive the reference can never hit); ref <= -2: a sphere or a box, primitive number -2 - ref, tested through its table.  A
 // record without a triangle has NaN vertices, which fail the triangle test.
-// entry: the record unit of the node `entry levels` above this leaf (of the root where the tree is shallower; 0 = the root).  A ray
-// that starts ON this primitive - a shadow ray, a scattered ray - is first walked through that node's subtree alone, where
-// most such rays end (DScene::entry_levels, wavefront.hip).
 struct alignas(64) DLeaf {
   float v[9];
   int32_t ref;
-  int32_t entry;
-  int32_t pad[5];
+  int32_t pad[6];
 };
 static_assert(sizeof(DLeaf) == 64, "leaf record");
 constexpr int kLeafMaxPrims = 1;
-#ifndef RTX_ENTRY_LEVELS
-#define RTX_ENTRY_LEVELS 3
-#endif
-constexpr int kEntryLevels = RTX_ENTRY_LEVELS;   // default of DScene::entry_levels
 constexpr int kWalkDone = 0x7fffffff;
 // Words of stack a walk of a tree of `levels` node levels can need: one three-word entry per level, and one to spare.
 constexpr int walk_stack_slots(int levels) { return 2 * (levels + 1); }
@@ -106,7 +98,6 @@ template <class R> struct DScene {
   float wt_anchor[3], wt_step[3];                      // the grid the node origins of the eight-wide tree lie on (DNode8::org)
   int32_t n_spheres, n_planes, n_tris, n_boxes, n_points, n_quads, n_disks, n_mats, n_images, n_emissive;
   int32_t n_nodes, n_prims, n_nodes8, n_leaves8, walk_levels;
-  int32_t entry_levels;                                // how many levels above a leaf DLeaf::entry points (0: every entry is the root)
   int32_t n_nmaps;                                     // materials with a normal map (picks the kernel instances that apply them)
   DEnv<R> env;
 };
@@ -148,7 +139,7 @@ template <class R> struct DPhotonNode { R p[3]; int32_t axis; };       // kd-tre
 template <class R> struct DPhotonData { R dir[3]; R power[3]; };
 template <class R> struct DPhotonBox { R lo[3]; R hi[3]; };
 
-struct DCounters { unsigned long long samples, closest, shadow, segments, nodes_visited, prims_tested, nodes_visited_shadow, prims_tested_shadow; };
+struct DCounters { unsigned long long samples, closest, shadow, segments, nodes_visited, prims_tested; };
 
 // One closest-hit answer in the layout of rtx_hit (include/rtx_hip.h).
 struct DHitOut {

@@ -605,7 +605,6 @@ static int render_collect(rtx_ctx* c, rtx_stats* stats) {
   st.samples = hc.samples; st.rays_closest = hc.closest; st.rays_shadow = hc.shadow; st.segments = hc.segments;
   if (pd.photon_map_reused) st.rays_closest += c->ph_map.closest;   // the queries this film's photon map was traced with, made by an earlier call
   st.nodes_visited = hc.nodes_visited; st.prims_tested = hc.prims_tested;
-  st.nodes_visited_shadow = hc.nodes_visited_shadow; st.prims_tested_shadow = hc.prims_tested_shadow;
   if (pd.wavefront) st.seconds_extend = c->wf.timed_seconds();
   st.seconds_render = ms * 1e-3;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->evm));
@@ -625,7 +624,8 @@ static void settle(rtx_ctx* c) {
 // counters to pinned host memory) on the stream; render_collect finishes it.  `no_alloc`: the render may not allocate
 // (rtx_render_device_noalloc): its chunk sums and counters go to the device's scratch array, and whatever would need another
 // buffer is refused; with `bare` as well it records nothing but kernels (no event, no copy) and leaves nothing to collect.
-static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, bool no_alloc = false, bool bare = false) {
+static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, bool no_alloc = false, bool bare = false,
+                          bool stream_as_given = false /* NULL is HIP's default stream, not the context's own */) {
   if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
   settle(c);
   if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "render before upload_scene");
@@ -646,7 +646,7 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
   if (!host_out && !dev_out) return fail(RTX_ERR_INVALID_ARGUMENT, "output buffer is NULL");
   HIP_TRY(hipSetDevice(c->device));
   auto wall0 = std::chrono::steady_clock::now();
-  hipStream_t stream = user_stream ? user_stream : c->stream;
+  hipStream_t stream = (user_stream || stream_as_given) ? user_stream : c->stream;
 
   DRenderParams P;
   memset(&P, 0, sizeof P);
@@ -969,7 +969,6 @@ static int render_multi(rtx_ctx* c, const rtx_settings* s, float* host_out, void
       const rtx_stats& a = sh[k].st;
       t.samples += a.samples; t.rays_closest += a.rays_closest; t.rays_shadow += a.rays_shadow; t.segments += a.segments;
       t.nodes_visited += a.nodes_visited; t.prims_tested += a.prims_tested; t.kernel_launches += a.kernel_launches;
-      t.nodes_visited_shadow += a.nodes_visited_shadow; t.prims_tested_shadow += a.prims_tested_shadow;
       // the devices run side by side: the call takes as long as the slowest
       t.seconds_render = std::max(t.seconds_render, a.seconds_render); t.seconds_main_kernel = std::max(t.seconds_main_kernel, a.seconds_main_kernel);
       t.seconds_photon_pass = std::max(t.seconds_photon_pass, a.seconds_photon_pass); t.seconds_extend = std::max(t.seconds_extend, a.seconds_extend);
@@ -1026,9 +1025,8 @@ int rtx_render_device(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* 
 
 int rtx_render_device_async(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* hip_stream) {
   if (!d_out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "d_out_rgb is NULL");
-  if (!hip_stream) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_device_async needs the caller's stream (hip_stream is NULL)");
   if (c && c->multi) return fail(RTX_ERR_UNSUPPORTED, "the asynchronous render takes a single-device context (rtx_create)");
-  return guarded([&] { return render_enqueue(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream); });
+  return guarded([&] { return render_enqueue(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, false, false, true); });
 }
 
 int rtx_render_wait(rtx_ctx* c, rtx_stats* stats) {

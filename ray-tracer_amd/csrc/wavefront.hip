@@ -39,10 +39,6 @@ struct WfArrays {
   uint32_t *bflags, *xy, *pixel, *sample, *s_end, *cur, *next;
   float *hit_t, *hit_ua, *hit_ub;
   int32_t *hit_id, *hit_uv;          // type << kIdBits | idx (or -1);  uv_kind << kIdBits | uv_idx
-  // Entry points (tree scenes): the node a walk starts at instead of the root.  hit_entry: DLeaf::entry of the closest bounded
-  // primitive wf_extend found; ray_entry: where the slot's next closest-hit walk starts (its ray leaves that primitive);
-  // sh_entry: the same for a queued shadow ray.  0 = the root.
-  int32_t *hit_entry, *ray_entry, *sh_entry;
   uint32_t* q[2];
   uint32_t* sh_slot;
   float* sh[7];                       // origin, direction, t_max
@@ -94,7 +90,7 @@ constexpr int kLeafBatch = RTX_LEAF_BATCH;
 #ifndef RTX_POOL_MULT
 #define RTX_POOL_MULT 128   // path slots per resident lane (164 B each: 11 GB at most on 256 CUs); 10 M triangles at 1080p x 64 spp: 16: 839 ms, 32: 762, 64 and up (every work item in flight): 721
 #endif
-constexpr int kWfArrays = 6 + 3 + 3 + 3 + 1 + 7 + 3 + 2 + 3 + 2 + 1 + 7 + 3 + 4;   // 4-byte arrays of n_slots entries
+constexpr int kWfArrays = 6 + 3 + 3 + 3 + 1 + 7 + 3 + 2 + 2 + 1 + 7 + 3 + 4;   // 4-byte arrays of n_slots entries
 
 // Queue appends of the streaming kernels (wf_start, wf_shade): every thread of the workgroup reaches the call (they synchronise
 // the workgroup), ONE returning atomic per workgroup and queue.  Returning atomics on one address serialise at about 11 ns each
@@ -206,7 +202,6 @@ __global__ __launch_bounds__(kStreamBlock) void wf_start(DCamera<float> cam, DRe
     A.acc[0][sl] = 0.f; A.acc[1][sl] = 0.f; A.acc[2][sl] = 0.f;
     A.bsdf_pdf[sl] = 0.f;
     A.bflags[sl] = F_ALIVE;
-    A.ray_entry[sl] = 0;
   }
   const uint32_t at = block_append(bs, &ctl->n_q_[0].v, live);
   if (live) A.q[0][at] = sl;
@@ -310,16 +305,10 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
   Cand<float> c;
   Walk8 w;
   cand_init(c, 1e9f);
-  w.node = kWalkDone; w.sp = 0; w.best_p = -1; w.best_anc = 0; w.inv = {0.f, 0.f, 0.f};
+  w.node = kWalkDone; w.sp = 0; w.best_p = -1; w.inv = {0.f, 0.f, 0.f};
   int state = 0;   // 0 no ray, 1 walking, 2 walk finished, result not yet stored
-  // A ray that leaves a primitive is walked in two passes: first through the subtree of that primitive's entry point (a few levels
-  // above its leaf), which finds the hit of most such rays, then from the root with the interval that hit leaves, the subtree
-  // already searched skipped.  entry = that subtree's node (0: one pass from the root); second = the second pass is under way.
-  int entry = 0;
-  bool second = false;
   // the next ray, loaded while the current one is walked, so that a lane changes rays without waiting on memory
   uint32_t nslot = 0;
-  int nentry = 0;
   Ray<float> nray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
   bool have_next = false;
   for (;;) {
@@ -340,13 +329,12 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
         }
         A.hit_t[slot] = t; A.hit_id[slot] = id;
         if constexpr (MODE == MODE_TREE_UV) { A.hit_ua[slot] = ua; A.hit_ub[slot] = ub; A.hit_uv[slot] = uv; }
-        if (tree) A.hit_entry[slot] = w.best_anc;
         state = 0;
       }
       if (state == 0 && have_next) {   // take over the prefetched ray
         slot = nslot; ray = nray;
         cand_init(c, 1e9f);
-        if (tree) { walk8_begin(w, ray); entry = nentry; second = false; w.node = entry; }
+        if (tree) walk8_begin(w, ray);
         state = 1; have_next = false;
       }
       const uint32_t e = feed_take(feed, &ctl->cursor_rays_.v, !have_next, n);
@@ -354,7 +342,6 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
         nslot = order[e];
         nray.o = {A.ray[0][nslot], A.ray[1][nslot], A.ray[2][nslot]};
         nray.d = {A.ray[3][nslot], A.ray[4][nslot], A.ray[5][nslot]};
-        if (tree) nentry = A.ray_entry[nslot];
         have_next = true;
       }
       if (__ballot(state == 1 || have_next) == 0ull) break;
@@ -364,7 +351,6 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
     } else if (!tree) {
       if (state == 1) { walk_bounded<float, false>(sc, ray, 0.001f, c, st); state = 2; }
     } else {
-      if (second && w.node == entry) w.node = walk8_pop(w, st);   // searched in the first pass
       const bool inner = state == 1 && walk8_at_inner(w);
 #ifdef RTX_WALK_STATS
       { const unsigned long long mi = __ballot(inner); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_walk_stats[0], 1ull); if (mi) { atomicAdd(&g_walk_stats[1], 1ull); atomicAdd(&g_walk_stats[2], (unsigned long long)__popcll(mi)); } } }
@@ -378,10 +364,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
 #endif
         if (leaf) { walk8_leaf<false>(sc, ray, 0.001f, c, w, st); ++n_prims; }
       }
-      if (state == 1 && w.node == kWalkDone) {
-        if (entry != 0 && !second) { second = true; w.node = 0; w.sp = 0; }   // the rest of the tree, with the interval the first pass leaves
-        else state = 2;
-      }
+      if (state == 1 && w.node == kWalkDone) state = 2;
     }
   }
 #pragma unroll
@@ -440,7 +423,6 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
   float sh_tmax = 0.f;
   V3<float> sh_contrib = {0.f, 0.f, 0.f};
   uint32_t slot = 0, sh_target = 0;
-  int vertex_entry = 0;        // entry point of rays that leave this vertex (0: it lies on no bounded primitive)
   bool live = false, started = false;   // the slot has a ray to trace next; it began a new sample
   if (valid) {
   slot = A.q[turn.q_in][i];
@@ -456,8 +438,6 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
   PathKey key = {pixel, P.seed, s - 1u, (uint32_t)P.rng};
   Hit<float> rec;
   const bool hit = wf_load_hit<MODE>(sc, A, slot, ps.ray, rec);
-  if (MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims && hit && (rec.type == PRIM_TRIANGLE || rec.type == PRIM_SPHERE || rec.type == PRIM_BOX))
-    vertex_entry = A.hit_entry[slot];
   did = path_vertex<float, NMAP>(ps, hit, rec, sc, mats, P, key, [&](const Ray<float>& sr, float t_max, V3<float> contrib) {
     cast = true; sh_ray = sr; sh_tmax = t_max; sh_contrib = contrib;
   });
@@ -498,7 +478,6 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
     A.acc[0][slot] = ps.acc.x; A.acc[1][slot] = ps.acc.y; A.acc[2][slot] = ps.acc.z;
     A.bsdf_pdf[slot] = ps.bsdf_pdf;
     A.bflags[slot] = ps.bounce_flags;
-    if (MODE != MODE_FLAT) A.ray_entry[slot] = started ? 0 : vertex_entry;   // a camera ray starts at the root
   }
   }
   uint32_t k, at;
@@ -508,7 +487,6 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
     A.sh[0][k] = sh_ray.o.x; A.sh[1][k] = sh_ray.o.y; A.sh[2][k] = sh_ray.o.z;
     A.sh[3][k] = sh_ray.d.x; A.sh[4][k] = sh_ray.d.y; A.sh[5][k] = sh_ray.d.z; A.sh[6][k] = sh_tmax;
     A.sh_c[0][k] = sh_contrib.x; A.sh_c[1][k] = sh_contrib.y; A.sh_c[2][k] = sh_contrib.z;
-    if (MODE != MODE_FLAT) A.sh_entry[k] = vertex_entry;
   }
   if (live) A.q[turn.q_out][at] = slot;
   block_count4(bs, banks, (did & STEP_SHADED) != 0, (did & STEP_SHADOW) != 0, live, started);
@@ -516,9 +494,8 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<float> sc, WfArrays A, WfControl* ctl, int sh /* the shadow queue's counter */, float* __restrict__ partial, int stack_levels,
-                                                     const uint32_t* __restrict__ order /* shadow-queue indices in the order to take them, or NULL = as queued */, DCounters* counters) {
+                                                     const uint32_t* __restrict__ order /* shadow-queue indices in the order to take them, or NULL = as queued */) {
   const uint32_t n = ctl->n_shadow_[sh].v;
-  uint32_t n_nodes = 0, n_prims = 0;   // node records and leaf records this lane fetched
   WaveFeed feed = {0u, 0u, false};
   LaneStack st = lane_stack(0);
   const bool tree = MODE != MODE_FLAT && sc.n_prims > kLinearMaxPrims;
@@ -528,12 +505,8 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<
   Cand<float> c;
   Walk8 w;
   cand_init(c, 1e9f);
-  w.node = kWalkDone; w.sp = 0; w.best_p = -1; w.best_anc = 0; w.inv = {0.f, 0.f, 0.f};
+  w.node = kWalkDone; w.sp = 0; w.best_p = -1; w.inv = {0.f, 0.f, 0.f};
   int state = 0;   // 0 no ray, 1 walking, 2 finished (occluded), 3 finished (visible)
-  // Two passes, as in wf_extend: the subtree around the primitive the ray leaves first - any hit there ends the query, and in a
-  // scene dense enough to need a tree that is where most shadow rays end -, the rest of the tree only for rays it lets through.
-  int entry = 0, nentry = 0;
-  bool second = false;
   uint32_t ni = 0;   // the next shadow ray, loaded while the current one is walked
   float nt_max = 0.f;
   Ray<float> nsr = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
@@ -554,7 +527,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<
       if (state == 0 && have_next) {
         i = ni; sr = nsr; t_max = nt_max;
         cand_init(c, t_max);
-        if (tree) { walk8_begin(w, sr); entry = nentry; second = false; w.node = entry; }
+        if (tree) walk8_begin(w, sr);
         state = 1; have_next = false;
       }
       const uint32_t e = feed_take(feed, &ctl->cursor_shadow_.v, !have_next, n);
@@ -563,7 +536,6 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<
         nsr.o = {A.sh[0][ni], A.sh[1][ni], A.sh[2][ni]};
         nsr.d = {A.sh[3][ni], A.sh[4][ni], A.sh[5][ni]};
         nt_max = A.sh[6][ni];
-        if (tree) nentry = A.sh_entry[ni];
         have_next = true;
       }
       if (__ballot(state == 1 || have_next) == 0ull) break;
@@ -573,28 +545,14 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<
     } else if (!tree) {
       if (state == 1) state = occluded(sc, sr, 0.001f, t_max, st) ? 2 : 3;
     } else {
-      if (second && w.node == entry) w.node = walk8_pop(w, st);   // searched in the first pass
       const bool inner = state == 1 && walk8_at_inner(w);
-      if (inner) { walk8_inner<false>(sc, sr, 0.001f, c.t, w, st); ++n_nodes; }   // any hit ends the query: no nearest-first order
+      if (inner) walk8_inner<false>(sc, sr, 0.001f, c.t, w, st);   // any hit ends the query: no nearest-first order
       const bool leaf = state == 1 && walk8_at_leaf(w);
       if (kLeafBatch <= 1 || __popcll(__ballot(leaf)) >= kLeafBatch || __ballot(state == 1 && walk8_at_inner(w)) == 0ull) {
-        if (leaf) { walk8_leaf<true>(sc, sr, 0.001f, c, w, st); ++n_prims; }
+        if (leaf) walk8_leaf<true>(sc, sr, 0.001f, c, w, st);
       }
-      if (state == 1 && w.node == kWalkDone) {   // (wf_shade has tested the planes and lights)
-        if (c.type >= 0) state = 2;
-        else if (entry != 0 && !second) { second = true; w.node = 0; w.sp = 0; }
-        else state = 3;
-      }
+      if (state == 1 && w.node == kWalkDone) state = c.type >= 0 ? 2 : 3;   // (wf_shade has tested the planes and lights)
     }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    n_nodes += (uint32_t)__shfl_xor((int)n_nodes, off, 64);
-    n_prims += (uint32_t)__shfl_xor((int)n_prims, off, 64);
-  }
-  if ((threadIdx.x & 63) == 0 && (n_nodes | n_prims)) {
-    atomicAdd(&counters->nodes_visited_shadow, (unsigned long long)n_nodes);
-    atomicAdd(&counters->prims_tested_shadow, (unsigned long long)n_prims);
   }
 }
 
@@ -625,7 +583,7 @@ template <int MODE> void launch_turn_kernels(const DScene<float>& sc, const DCam
     } else if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, cam, P, A, ctl, *turn, partial, banks);
     else hipLaunchKernelGGL((wf_shade<MODE, false>), g, bs, 0, stream, sc, cam, P, A, ctl, *turn, partial, banks);
     if (sorted) sort_queue(0, turn->sh, 1);
-    hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, turn->sh, partial, stack_levels, sorted ? A.order_out : nullptr, counters);
+    hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, turn->sh, partial, stack_levels, sorted ? A.order_out : nullptr);
     launches += 2;
   }
   if (sorted) sort_queue(q_out, n_out, 0);
@@ -683,7 +641,6 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
     A.bflags = nextu(); A.xy = nextu(); A.pixel = nextu(); A.sample = nextu(); A.s_end = nextu(); A.cur = nextu(); A.next = nextu();
     A.hit_t = nextf(); A.hit_ua = nextf(); A.hit_ub = nextf();
     A.hit_id = (int32_t*)nextu(); A.hit_uv = (int32_t*)nextu();
-    A.hit_entry = (int32_t*)nextu(); A.ray_entry = (int32_t*)nextu(); A.sh_entry = (int32_t*)nextu();
     A.q[0] = nextu(); A.q[1] = nextu();
     A.sh_slot = nextu();
     for (auto& p : A.sh) p = nextf();

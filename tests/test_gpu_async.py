@@ -1,6 +1,5 @@
 """Additions of the C ABI that change HOW a render runs, never its result: the two-halves render (rtx_render_device_async /
-rtx_render_wait), the entry points of the queue pipeline's tree walks (rays that leave a primitive start a few levels above its
-leaf), the smaller pools the queue pipeline falls back to, and the RCCL film gather of a multi-device context.  Every film must
+rtx_render_wait), the smaller pools the queue pipeline falls back to, and the RCCL film gather of a multi-device context.  Every film must
 equal the plain one bit for bit."""
 import os
 
@@ -54,6 +53,13 @@ def test_async_render_equals_synchronous_render(pkg, load_scene):
         pt.render_wait()
     lib = abi.load_library()
     assert lib.rtx_render_device_async(pt._ctx, None, None, None) == -1
+    # a stream of the caller's own
+    side = torch.cuda.Stream()
+    g.fill_(-1.0)
+    torch.cuda.synchronize()
+    pt.render_device_async(g.data_ptr(), side.cuda_stream)
+    pt.render_wait()
+    assert np.array_equal(_bits(g), _bits(want[0]))
     for pt in tracers:
         pt.close()
 
@@ -63,7 +69,7 @@ def _queue_film(pkg, sd, env, **kw):
     os.environ.update(env)
     try:
         with pkg.renderer.HipPathTracer(0) as pt:
-            pt.upload_scene(sd)                      # RTX_ENTRY_LEVELS is read here, RTX_POOL_MULT at the render
+            pt.upload_scene(sd)                      # (RTX_POOL_MULT is read at the render)
             pt.set_camera(sd.camera(kw["width"], kw["height"]))
             pt.set_settings(sd.settings(pipeline=pkg.abi.PIPELINE_WAVEFRONT, **kw))
             film = pt.render().copy()
@@ -76,19 +82,15 @@ def _queue_film(pkg, sd, env, **kw):
                 os.environ[k] = v
 
 
-def test_entry_points_change_the_work_not_the_film(pkg, load_scene):
+def test_a_smaller_pool_gives_the_same_film(pkg, load_scene):
+    """The queue pipeline halves its pool of path slots when the device cannot give the full one (RTX_POOL_MULT caps the first try):
+    slots are reused more often, the film is the same."""
     sd = soup_scene(pkg, load_scene, n=60000)
-    kw = dict(width=120, height=68, samples_per_pixel=8, max_depth=8, seed=21)
-    base, st0 = _queue_film(pkg, sd, {"RTX_ENTRY_LEVELS": "0"}, **kw)    # every walk starts at the root
-    assert st0.nodes_visited > 0 and st0.nodes_visited_shadow > 0
-    for levels in ("1", "2", "3", "5", "16"):
-        film, st = _queue_film(pkg, sd, {"RTX_ENTRY_LEVELS": levels}, **kw)
-        assert np.array_equal(film.view(np.uint32), base.view(np.uint32)), levels
-        assert (st.samples, st.rays_closest, st.rays_shadow, st.segments) == (st0.samples, st0.rays_closest, st0.rays_shadow, st0.segments)
-    # a tenth of the pool: slots are reused more often, the film is the same
-    film, _ = _queue_film(pkg, sd, {"RTX_POOL_MULT": "1"}, width=640, height=360, samples_per_pixel=16, max_depth=6, seed=2)
-    want, _ = _queue_film(pkg, sd, {}, width=640, height=360, samples_per_pixel=16, max_depth=6, seed=2)
+    kw = dict(width=640, height=360, samples_per_pixel=16, max_depth=6, seed=2)
+    film, st = _queue_film(pkg, sd, {"RTX_POOL_MULT": "1"}, **kw)
+    want, st0 = _queue_film(pkg, sd, {}, **kw)
     assert np.array_equal(film.view(np.uint32), want.view(np.uint32))
+    assert (st.samples, st.rays_closest, st.rays_shadow, st.segments) == (st0.samples, st0.rays_closest, st0.rays_shadow, st0.segments)
 
 
 def test_rccl_gather_of_a_multi_device_context(pkg, load_scene):
