@@ -141,6 +141,11 @@ typedef struct rtx_settings {
   float caustic_gather_radius;              /* gather radius, a float in the reference too (default 0.1f) */
 } rtx_settings;
 
+/* rtx_stats::flags.  RTX_STAT_BEFORE_TREE: the frame was rendered while the reference-order tree of a large scene was still being
+ * built on the host (rtx_upload_scene returns before it is done, see there): exact ties in t between two bounded primitives went by
+ * primitive number and were counted.  RTX_STAT_RENDERED_TWICE: there was such a tie, so the call waited for the tree and rendered
+ * the frame again with the reference's tie order (the film is that second one; seconds_total covers both). */
+enum { RTX_STAT_BEFORE_TREE = 1, RTX_STAT_RENDERED_TWICE = 2 };
 typedef struct rtx_stats {
   uint64_t samples;          /* camera paths started */
   uint64_t rays_closest;     /* closest-hit queries executed */
@@ -152,7 +157,7 @@ typedef struct rtx_stats {
   uint32_t kernel_launches;
   uint32_t pipeline_used;    /* RTX_PIPELINE_FUSED or _WAVEFRONT */
   uint32_t precision_used;   /* RTX_PRECISION_* the render ran in */
-  uint32_t reserved_;
+  uint32_t flags;            /* RTX_STAT_*: how the call went */
   double seconds_photon_pass;/* PathPhoton: wall time of the photon pass (trace kernel, kd-tree build on the host, uploads); ~0 when the context reuses the
                               * map of an earlier render (same scene upload, seed, generator, caustic_photon_count, precision); else 0.  rays_closest
                               * includes the pass's queries in both cases */
@@ -209,7 +214,15 @@ int rtx_multi_set_gather(rtx_ctx* ctx, int mode);
 /* Replaces GPUPathTracer::upload_scene (cuda_api.hpp:84-89; cuda_pathtracer.cu:234-318).
  * Copies the description, builds both BVHs (the reference-order binary tree of
  * engine/bvh.hpp:148-218 for validation, and the wide one the integrator traverses) and
- * the environment-map sampling tables (engine/texture.hpp:403-473). */
+ * the environment-map sampling tables (engine/texture.hpp:403-473).
+ * Scenes of 2^18 or more bounded primitives: the call returns when the tables and the wide tree are on the device(s); the
+ * reference-order tree is finished by a host thread of the library's own (it reads nothing of the caller's any more).  The
+ * single-precision path tracer needs that tree only to decide exact ties in t the reference's way, so it renders at once: a frame
+ * in which such a tie occurs is rendered again when the tree is there (rtx_stats::flags), every film is the one the finished tree
+ * gives.  Whatever walks the reference-order tree itself - rtx_trace_closest*, double precision, the other render modes,
+ * rtx_get_bvh_info, rtx_get_reference_bvh - waits for it.  A scene in which a primitive's box is flat along an axis is built the
+ * ordinary way (the reference cannot reach some such primitives, which the wide tree has to know), as is every scene when the
+ * environment variable RTX_EAGER_TREE is set. */
 int rtx_upload_scene(rtx_ctx* ctx, const rtx_scene_desc* scene);
 
 /* Replaces GPUPathTracer::set_camera (cuda_api.hpp:99).  Takes the vectors of an already

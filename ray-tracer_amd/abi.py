@@ -89,7 +89,7 @@ class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("segments", C.c_uint64), ("seconds_render", C.c_double), ("seconds_main_kernel", C.c_double), ("seconds_total", C.c_double),
                 ("kernel_launches", C.c_uint32), ("pipeline_used", C.c_uint32),
-                ("precision_used", C.c_uint32), ("reserved_", C.c_uint32), ("seconds_photon_pass", C.c_double),
+                ("precision_used", C.c_uint32), ("flags", C.c_uint32), ("seconds_photon_pass", C.c_double),
                 ("seconds_extend", C.c_double), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64)]
 
 
@@ -112,6 +112,7 @@ PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
 MODE_WHITTED, MODE_PATHTRACE, MODE_BDPT, MODE_PATHPHOTON = 0, 1, 2, 6
 RNG_AUTO, RNG_PHILOX, RNG_PCG4D = 0, 1, 2
 GATHER_PEER_COPY, GATHER_RCCL = 0, 1
+STAT_BEFORE_TREE, STAT_RENDERED_TWICE = 1, 2
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 

@@ -529,6 +529,16 @@ RTX_DEV bool leaf_tri_t(const float* v, const Ray<float>& r, float t_min, float 
   return fabsf(a) >= 1e-8f && u >= 0.f && u <= 1.f && vv >= 0.f && u + vv <= 1.f && t >= t_min && t <= t_max;
 }
 
+// Exact tie in t between primitive `p` and the current winner `best` (primitive numbers): does p win?  The later one in the
+// reference's leaf order does (Scene::hit accepts t == closest_so_far, ref: engine/scene.hpp:602-631).  While that order is
+// not on the device yet (the host is still building the reference-order tree) the higher primitive number wins and the tie is
+// counted, so that the host can render the frame again once the order is known (such ties are rare: it hardly ever has to).
+RTX_DEV bool tie_goes_to(const DScene<float>& sc, int p, int best) {
+  if (sc.rank) return sc.rank[p] > sc.rank[best];
+  if (sc.ties) atomicAdd(sc.ties, 1ull);
+  return p > best;
+}
+
 // Tests the primitive of the leaf record with code `leaf` (a ~unit) against the ray; updates the candidate and the tie state.
 RTX_DEV void walk8_leaf_test(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, Walk8& w, int leaf) {
   const uint4* rec = reinterpret_cast<const uint4*>(sc.nodes8 + (~leaf));
@@ -540,7 +550,7 @@ RTX_DEV void walk8_leaf_test(const DScene<float>& sc, const Ray<float>& r, float
   float t, u, vv;
   // (the range check on ref costs two instructions and keeps a record that is no leaf record from ever being taken for a triangle)
   bool ok = leaf_tri_t(v, r, t_min, c.t, t, u, vv) && (uint32_t)(ref - sc.n_spheres) < (uint32_t)sc.n_tris;
-  if (ok && t == c.t && w.best_p >= 0) ok = sc.rank[ref] > sc.rank[w.best_p];   // exact tie: the later one in the reference's order wins
+  if (ok && t == c.t && w.best_p >= 0) ok = tie_goes_to(sc, ref, w.best_p);   // exact tie: the later one in the reference's order wins
   if (ok) { c.t = t; c.type = PRIM_TRIANGLE; c.idx = ref - sc.n_spheres; c.uv_kind = 1; c.ua = u; c.ub = vv; w.best_p = ref; }
   const int p = -2 - ref;
   const bool sphere = (uint32_t)p < (uint32_t)sc.n_spheres, box = (uint32_t)(p - sc.n_spheres - sc.n_tris) < (uint32_t)sc.n_boxes;
@@ -550,7 +560,7 @@ RTX_DEV void walk8_leaf_test(const DScene<float>& sc, const Ray<float>& r, float
     Cand<float> trial = c;
     test_bounded(sc, type, idx, r, t_min, trial);
     const bool changed = trial.type == type && trial.idx == idx && (trial.t != c.t || c.type != type || c.idx != idx);
-    if (changed && !(trial.t == c.t && w.best_p >= 0 && sc.rank[p] < sc.rank[w.best_p])) { c = trial; w.best_p = p; }
+    if (changed && !(trial.t == c.t && w.best_p >= 0 && !tie_goes_to(sc, p, w.best_p))) { c = trial; w.best_p = p; }
   }
 }
 

@@ -2,6 +2,7 @@
 #include "pt_host.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstddef>
@@ -78,11 +79,9 @@ template <class F> void parallel_for(size_t n, F&& f) {
   for (std::thread& t : th) t.join();
 }
 
-// A primitive's box, numbered as the reference's primitive list (spheres, then triangles, then boxes), and what the median
-// splits move around: its centroid (ref: bvh.hpp:89-95) and that number.  32-byte keys instead of the reference's 56-byte
-// BVHPrimitive: std::nth_element makes the same comparisons and therefore the same moves, on fewer bytes.
-struct BuildBox { double lo[3], hi[3]; };
-struct BuildKey { double c[3]; int32_t number, pad; };
+// (BuildBox / BuildKey, pt_host.hpp: a primitive's box, numbered as the reference's primitive list, and what the median splits
+// move around: its centroid (ref: bvh.hpp:89-95) and that number.  32-byte keys instead of the reference's 56-byte BVHPrimitive:
+// std::nth_element makes the same comparisons and therefore the same moves, on fewer bytes.)
 
 size_t subtree_nodes(size_t count) {
   if (count <= 2) return 1;
@@ -284,11 +283,14 @@ template <class R> void fill_tree(DScene<R>& sc, std::vector<DeviceBuffer>& pool
   sc.n_nodes = (int)bvh.nodes.size(); sc.n_prims = (int)bvh.prims.size();
 }
 
-void HostBvh::build(const rtx_scene_desc& d) {
-  auto t0 = std::chrono::steady_clock::now();
-  nodes.clear(); prims.clear();
+size_t reference_tree_nodes(size_t n_prims) { return n_prims ? subtree_nodes(n_prims) : 0; }
+
+void make_build_input(const rtx_scene_desc& d, BuildInput& out) {
+  const auto t0 = std::chrono::steady_clock::now();
   const size_t ns = d.n_spheres, nt = d.n_triangles, nb = d.n_boxes;
-  Staging<BuildBox> bp(ns + nt + nb);
+  out.n_spheres = ns; out.n_tris = nt; out.n_boxes = nb;
+  Staging<BuildBox>& bp = out.boxes;
+  bp.resize(ns + nt + nb);
   for (size_t i = 0; i < ns; ++i) {   // ref: engine/scene.hpp:500-510
     BuildBox& p = bp[i];
     for (int a = 0; a < 3; ++a) { p.lo[a] = d.spheres[i].center[a] - d.spheres[i].radius; p.hi[a] = d.spheres[i].center[a] + d.spheres[i].radius; }
@@ -307,20 +309,40 @@ void HostBvh::build(const rtx_scene_desc& d) {
     BuildBox& p = bp[ns + nt + i];
     for (int a = 0; a < 3; ++a) { p.lo[a] = d.boxes[i].box_min[a]; p.hi[a] = d.boxes[i].box_max[a]; }
   }
+  out.keys.resize(bp.size());
+  std::atomic<bool> flat{false};
+  parallel_for(bp.size(), [&](size_t b, size_t e) {
+    bool f = false;
+    for (size_t i = b; i < e; ++i) {
+      for (int a = 0; a < 3; ++a) {
+        out.keys[i].c[a] = (bp[i].lo[a] + bp[i].hi[a]) * 0.5;   // ref: bvh.hpp:89-95
+        f = f || !(bp[i].lo[a] < bp[i].hi[a]);                   // flat (or inverted, or NaN) along this axis
+      }
+      out.keys[i].number = (int32_t)i; out.keys[i].pad = 0;
+    }
+    if (f) flat.store(true, std::memory_order_relaxed);
+  });
+  out.any_flat = flat.load();
+  out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void HostBvh::build(const rtx_scene_desc& d) {
+  BuildInput in;
+  make_build_input(d, in);
+  build_from(in);
+}
+
+void HostBvh::build_from(BuildInput& in) {
+  auto t0 = std::chrono::steady_clock::now();
+  nodes.clear(); prims.clear();
+  const size_t ns = in.n_spheres, nt = in.n_tris;
+  const Staging<BuildBox>& bp = in.boxes;
+  Staging<BuildKey>& keys = in.keys;
   const bool timing = getenv("RTX_TIMING") != nullptr;   // diagnostics: phase times on stderr
   auto lap = [&](const char* what) {
     if (timing) fprintf(stderr, "[rtx upload]   reference tree: %-28s %7.1f ms since its start\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
   };
-  lap("primitive boxes");
   if (!bp.empty()) {
-    Staging<BuildKey> keys(bp.size());
-    parallel_for(bp.size(), [&](size_t b, size_t e) {
-      for (size_t i = b; i < e; ++i) {
-        for (int a = 0; a < 3; ++a) keys[i].c[a] = (bp[i].lo[a] + bp[i].hi[a]) * 0.5;   // ref: bvh.hpp:89-95
-        keys[i].number = (int32_t)i; keys[i].pad = 0;
-      }
-    });
-    lap("centroid keys");
     nodes.resize(subtree_nodes(bp.size()));
     Builder b{bp, keys, nodes};
     b.build(0, 0, bp.size(), 0);
@@ -334,10 +356,11 @@ void HostBvh::build(const rtx_scene_desc& d) {
       }
     });
   }
-  seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  seconds = in.seconds + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 void HostScene::release() {
+  job.reset(); job_slot = -1;   // (the last scene to let go of a job waits for its thread)
   for (DeviceBuffer& b : pool) b.release();
   pool.clear();
   wide.release();
@@ -383,33 +406,121 @@ static std::vector<int32_t> emissive_spheres(const rtx_scene_desc& d) {
   return out;
 }
 
+// What the GPU-built tree takes from the reference-order tree: every primitive's position in the reference's leaf order (ties
+// in t go to the later one), and which primitives the reference can never hit (its slab test rejects a box that is flat along
+// an axis, ref: engine/bvh.hpp:43, so the primitives of such a leaf are unreachable there).
+static void derive_from_tree(size_t ns, size_t nt, ScenePrep& out) {
+  const HostBvh& bvh = out.bvh;
+  out.rank.clear(); out.dead.clear();
+  if (bvh.prims.size() <= (size_t)kLinearMaxPrims) return;
+  const size_t np = bvh.prims.size();
+  auto number = [&](const DPrimRef& p) -> size_t { return p.type == PRIM_SPHERE ? (size_t)p.index : p.type == PRIM_TRIANGLE ? ns + (size_t)p.index : ns + nt + (size_t)p.index; };
+  out.rank.resize(np);
+  parallel_for(np, [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) out.rank[number(bvh.prims[i])] = (int32_t)i; });
+  std::mutex mu;
+  parallel_for(bvh.nodes.size(), [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      const DNodeRef& n = bvh.nodes[i];
+      if (n.count <= 0 || (n.lo[0] != n.hi[0] && n.lo[1] != n.hi[1] && n.lo[2] != n.hi[2])) continue;
+      std::lock_guard<std::mutex> g(mu);
+      if (out.dead.empty()) out.dead.assign(np, 0);
+      for (int k = 0; k < n.count; ++k) out.dead[number(bvh.prims[(size_t)n.first + k])] = 1;
+    }
+  });
+}
+
 void build_scene_prep(const rtx_scene_desc& d, ScenePrep& out) {
   const bool timing = getenv("RTX_TIMING") != nullptr;   // diagnostics: phase times on stderr
   const auto t0 = std::chrono::steady_clock::now();
   out.bvh.build(d);
-  const HostBvh& bvh = out.bvh;
   out.emissive = emissive_spheres(d);
-  out.rank.clear(); out.dead.clear();
-  if (bvh.prims.size() > (size_t)kLinearMaxPrims) {
-    // What the GPU-built tree takes from the reference-order tree: every primitive's position in the reference's leaf order (ties
-    // in t go to the later one), and which primitives the reference can never hit (its slab test rejects a box that is flat along
-    // an axis, ref: engine/bvh.hpp:43, so the primitives of such a leaf are unreachable there).
-    const size_t np = bvh.prims.size(), ns = d.n_spheres, nt = d.n_triangles;
-    auto number = [&](const DPrimRef& p) -> size_t { return p.type == PRIM_SPHERE ? (size_t)p.index : p.type == PRIM_TRIANGLE ? ns + (size_t)p.index : ns + nt + (size_t)p.index; };
-    out.rank.resize(np);
-    parallel_for(np, [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) out.rank[number(bvh.prims[i])] = (int32_t)i; });
-    std::mutex mu;
-    parallel_for(bvh.nodes.size(), [&](size_t b, size_t e) {
-      for (size_t i = b; i < e; ++i) {
-        const DNodeRef& n = bvh.nodes[i];
-        if (n.count <= 0 || (n.lo[0] != n.hi[0] && n.lo[1] != n.hi[1] && n.lo[2] != n.hi[2])) continue;
-        std::lock_guard<std::mutex> g(mu);
-        if (out.dead.empty()) out.dead.assign(np, 0);
-        for (int k = 0; k < n.count; ++k) out.dead[number(bvh.prims[(size_t)n.first + k])] = 1;
-      }
-    });
-  }
+  derive_from_tree(d.n_spheres, d.n_triangles, out);
   if (timing) fprintf(stderr, "[rtx upload] %-28s %8.1f ms\n", "reference tree, ranks", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
+
+// ------------------------------------------------------------------------------------------
+// The reference-order tree in the background (RefTreeJob, pt_host.hpp)
+// ------------------------------------------------------------------------------------------
+struct RefTreeJob {
+  BuildInput in;
+  ScenePrep prep;
+  std::vector<int> devices;
+  std::vector<RefTreeBuffers> dev;
+  std::thread th;
+  std::atomic<bool> done{false};
+  std::mutex take_mutex;
+  bool joined = false;
+  int rc = RTX_OK;
+  std::string err;
+  double seconds = 0.0;
+  void run();
+  ~RefTreeJob() {
+    if (th.joinable()) th.join();
+    for (size_t k = 0; k < dev.size(); ++k) {   // what no scene took over
+      if (!dev[k].nodes.ptr && !dev[k].prims.ptr && !dev[k].rank.ptr) continue;
+      (void)hipSetDevice(devices[k]);
+      dev[k].nodes.release(); dev[k].prims.release(); dev[k].rank.release();
+    }
+  }
+};
+
+void RefTreeJob::run() {
+  const bool timing = getenv("RTX_TIMING") != nullptr;
+  if (const char* e = getenv("RTX_TREE_DELAY_MS")) {   // tests: keep the tree away for a while, so that renders run without it
+    const int ms = atoi(e);
+    if (ms > 0 && ms <= 60000) std::this_thread::sleep_for(std::chrono::milliseconds(ms));
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  try {
+    const size_t ns = in.n_spheres, nt = in.n_tris;
+    prep.bvh.build_from(in);
+    in = BuildInput();   // boxes and keys are no longer needed
+    derive_from_tree(ns, nt, prep);
+    seconds = prep.bvh.seconds;
+    // every device gets its copy, over a stream of this thread's own (the devices may be rendering)
+    for (size_t k = 0; k < devices.size() && rc == RTX_OK; ++k) {
+      hipStream_t stream = nullptr;
+      if (hipSetDevice(devices[k]) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { rc = RTX_ERR_HIP; err = "background upload: device or stream"; break; }
+      auto put = [&](DeviceBuffer& b, const void* src, size_t bytes) {
+        if (!b.ensure(bytes)) { rc = RTX_ERR_OUT_OF_MEMORY; err = "reference-order tree: device allocation"; return; }
+        if (bytes && hipMemcpyAsync(b.ptr, src, bytes, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = RTX_ERR_HIP; err = "reference-order tree: copy to the device"; }
+      };
+      put(dev[k].nodes, prep.bvh.nodes.data(), prep.bvh.nodes.size() * sizeof(DNodeRef));
+      if (rc == RTX_OK) put(dev[k].prims, prep.bvh.prims.data(), prep.bvh.prims.size() * sizeof(DPrimRef));
+      if (rc == RTX_OK) put(dev[k].rank, prep.rank.data(), prep.rank.size() * sizeof(int32_t));
+      if (hipStreamSynchronize(stream) != hipSuccess && rc == RTX_OK) { rc = RTX_ERR_HIP; err = "reference-order tree: copy to the device"; }
+      (void)hipStreamDestroy(stream);
+      dev[k].seconds = seconds;
+    }
+    if (rc == RTX_OK && !prep.dead.empty()) { rc = RTX_ERR_HIP; err = "internal: unreachable primitives in a scene without flat boxes"; }
+    prep = ScenePrep();   // the host copies are no longer needed
+  } catch (const std::bad_alloc&) { rc = RTX_ERR_OUT_OF_MEMORY; err = "host allocation failed (reference-order tree)";
+  } catch (const std::exception& e) { rc = RTX_ERR_HIP; err = e.what(); }
+  if (timing) fprintf(stderr, "[rtx upload] %-28s %8.1f ms (in the background)\n", "reference tree, ranks, copies", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  done.store(true, std::memory_order_release);
+}
+
+std::shared_ptr<RefTreeJob> start_ref_tree_job(BuildInput& in, const std::vector<int>& devices) {
+  if (in.boxes.size() < kLazyTreeMinPrims || in.any_flat || devices.empty() || getenv("RTX_EAGER_TREE") != nullptr) return nullptr;
+  std::shared_ptr<RefTreeJob> job(new RefTreeJob());
+  job->in = std::move(in);
+  job->devices = devices;
+  job->dev.resize(devices.size());
+  RefTreeJob* raw = job.get();   // the job outlives its thread: its destructor joins
+  job->th = std::thread([raw] { raw->run(); });
+  return job;
+}
+
+bool ref_tree_job_done(const RefTreeJob& job) { return job.done.load(std::memory_order_acquire); }
+
+int ref_tree_job_take(RefTreeJob& job, int slot, RefTreeBuffers& out, std::string& err) {
+  std::lock_guard<std::mutex> lock(job.take_mutex);   // the scenes of several devices may come at once
+  if (!job.joined) { if (job.th.joinable()) job.th.join(); job.joined = true; }
+  if (job.rc != RTX_OK) { err = job.err; return job.rc; }
+  if (slot < 0 || (size_t)slot >= job.dev.size()) { err = "internal: device slot"; return RTX_ERR_INVALID_ARGUMENT; }
+  out = job.dev[(size_t)slot];
+  job.dev[(size_t)slot] = RefTreeBuffers();   // ownership moves: DeviceBuffer is a plain handle
+  return RTX_OK;
 }
 
 int prepare_scene(const rtx_scene_desc& d, ScenePrep& out, std::string& err) {
@@ -465,6 +576,58 @@ int HostScene::upload_geometry(const rtx_scene_desc& d, std::string& err) {
   return RTX_OK;
 }
 
+int HostScene::upload_tree_deferred(const rtx_scene_desc& d, std::shared_ptr<RefTreeJob> j, int slot, std::string& err) {
+  UploadLap lap;
+  const size_t n = d.n_spheres + d.n_triangles + d.n_boxes;
+  n_prims = (int)n; n_nodes = (int)reference_tree_nodes(n);
+  build_seconds = 0.0;
+  // the trees themselves arrive with adopt_tree
+  dev_d.nodes = nullptr; dev_d.prims = nullptr; dev_d.n_nodes = n_nodes; dev_d.n_prims = n_prims;
+  dev_f.nodes = nullptr; dev_f.prims = nullptr; dev_f.n_nodes = n_nodes; dev_f.n_prims = n_prims;
+  dev_ref.nodes = nullptr; dev_ref.prims = nullptr; dev_ref.n_nodes = n_nodes; dev_ref.n_prims = n_prims;
+  dev_f.rank = nullptr;
+  job = std::move(j); job_slot = slot;
+  const int rc = build_walk_tree(nullptr, err);
+  lap("eight-wide tree (GPU)");
+  return rc;
+}
+
+int HostScene::adopt_tree(bool wait, std::string& err) {
+  if (!job) return RTX_OK;
+  if (!wait && !ref_tree_job_done(*job)) return RTX_OK;
+  RefTreeBuffers b;
+  const int rc = ref_tree_job_take(*job, job_slot, b, err);
+  job.reset(); job_slot = -1;
+  if (rc != RTX_OK) return rc;
+  pool.push_back(b.nodes); pool.push_back(b.prims); pool.push_back(b.rank);   // the scene owns them from here on
+  const DNodeRef* d_nodes = (const DNodeRef*)b.nodes.ptr;
+  const DPrimRef* d_prims = (const DPrimRef*)b.prims.ptr;
+  dev_d.nodes = d_nodes; dev_d.prims = d_prims; dev_f.prims = d_prims;
+  dev_ref.nodes = d_nodes; dev_ref.prims = d_prims;
+  dev_f.rank = (const int32_t*)b.rank.ptr;
+  build_seconds = b.seconds;
+  return RTX_OK;
+}
+
+// The eight-wide tree of the single-precision kernels, built on the current device from the single-precision tables.
+int HostScene::build_walk_tree(const uint8_t* d_dead, std::string& err) {
+  std::string berr;
+  const int rc = build_wide_tree(dev_f, d_dead, wide, berr);
+  if (rc != RTX_OK) { release(); err = berr; return rc; }
+  if (wide.levels > kMaxWalkLevels) {
+    err = "the traversal tree of this scene is " + std::to_string(wide.levels) + " levels deep (at most " + std::to_string(kMaxWalkLevels) + " are walked)";
+    release();
+    return RTX_ERR_UNSUPPORTED;
+  }
+  dev_f.nodes8 = (const DNode8*)wide.nodes.ptr;
+  dev_f.n_nodes8 = wide.n_nodes; dev_f.n_leaves8 = wide.n_leaves; dev_f.walk_levels = wide.levels;
+  for (int a = 0; a < 3; ++a) {
+    dev_f.bb_lo[a] = wide.lo[a]; dev_f.bb_scale[a] = wide.hi[a] > wide.lo[a] ? 128.0f / (wide.hi[a] - wide.lo[a]) : 0.f;
+    dev_f.wt_anchor[a] = wide.anchor[a]; dev_f.wt_step[a] = wide.step[a];
+  }
+  return RTX_OK;
+}
+
 int HostScene::upload_tree(const rtx_scene_desc& d, const ScenePrep& prep, std::string& err) {
   UploadLap lap;
   const HostBvh& bvh = prep.bvh;
@@ -482,20 +645,8 @@ int HostScene::upload_tree(const rtx_scene_desc& d, const ScenePrep& prep, std::
     const uint8_t* d_dead = prep.dead.empty() ? nullptr : push(pool, prep.dead, ok);
     lap("ranks and unreachable primitives");
     if (ok) {
-      std::string berr;
-      const int rc = build_wide_tree(dev_f, d_dead, wide, berr);
-      if (rc != RTX_OK) { release(); err = berr; return rc; }
-      if (wide.levels > kMaxWalkLevels) {
-        err = "the traversal tree of this scene is " + std::to_string(wide.levels) + " levels deep (at most " + std::to_string(kMaxWalkLevels) + " are walked)";
-        release();
-        return RTX_ERR_UNSUPPORTED;
-      }
-      dev_f.nodes8 = (const DNode8*)wide.nodes.ptr;
-      dev_f.n_nodes8 = wide.n_nodes; dev_f.n_leaves8 = wide.n_leaves; dev_f.walk_levels = wide.levels;
-      for (int a = 0; a < 3; ++a) {
-        dev_f.bb_lo[a] = wide.lo[a]; dev_f.bb_scale[a] = wide.hi[a] > wide.lo[a] ? 128.0f / (wide.hi[a] - wide.lo[a]) : 0.f;
-        dev_f.wt_anchor[a] = wide.anchor[a]; dev_f.wt_step[a] = wide.step[a];
-      }
+      const int rc = build_walk_tree(d_dead, err);
+      if (rc != RTX_OK) return rc;
     }
     lap("eight-wide tree (GPU)");
   }

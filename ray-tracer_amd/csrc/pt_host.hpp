@@ -32,6 +32,20 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
 };
 template <class T> using Staging = std::vector<T, NoInitAlloc<T>>;
 
+// What the reference-order build takes from the scene description: every bounded primitive's box and the key the median
+// splits move around (its centroid and its number in the reference's primitive list: spheres, then triangles, then boxes).
+// Once this is made the caller's arrays are no longer needed.
+struct BuildBox { double lo[3], hi[3]; };
+struct BuildKey { double c[3]; int32_t number, pad; };
+struct BuildInput {
+  Staging<BuildBox> boxes;
+  Staging<BuildKey> keys;
+  size_t n_spheres = 0, n_tris = 0, n_boxes = 0;
+  bool any_flat = false;    // some primitive's box is flat along an axis (only such primitives can be unreachable for the reference)
+  double seconds = 0.0;     // time it took to make
+};
+void make_build_input(const rtx_scene_desc& d, BuildInput& out);
+
 // The reference-order BVH on the host (ref: engine/bvh.hpp:148-218 over the primitive list
 // of engine/scene.hpp:496-533).
 struct HostBvh {
@@ -39,7 +53,9 @@ struct HostBvh {
   Staging<DPrimRef> prims;
   double seconds = 0.0;
   void build(const rtx_scene_desc& d);
+  void build_from(BuildInput& in);   // consumes the keys
 };
+size_t reference_tree_nodes(size_t n_prims);   // node count of the reference-order tree over n primitives (a function of n alone)
 
 // The eight-wide tree of the single-precision kernels, built on the GPU (bvh_build.hip).
 struct WideTree {
@@ -69,6 +85,22 @@ int validate_scene(const rtx_scene_desc& d, std::string& err);
 void build_scene_prep(const rtx_scene_desc& d, ScenePrep& out);
 int prepare_scene(const rtx_scene_desc& d, ScenePrep& out, std::string& err);
 
+// The reference-order tree of a LARGE scene, built on a host thread of its own after rtx_upload_scene has returned.  The single-
+// precision kernels need that tree only for exact ties in t (DScene::rank) and for the primitives the reference can never hit -
+// and those need a primitive with a flat box, which is checked up front -, so such a scene renders at once; the double-precision
+// kernels, the validation entry points and a frame in which a tie did occur wait for it.  The thread builds the tree, derives the
+// ranks and copies nodes, primitives and ranks to every device of the upload (on a stream of its own); HostScene::adopt_tree then
+// only takes the buffers over.
+struct RefTreeJob;
+struct RefTreeBuffers { DeviceBuffer nodes, prims, rank; double seconds = 0.0; };
+// NULL when the scene is built the ordinary way: fewer than kLazyTreeMinPrims bounded primitives, a primitive with a flat box, or
+// RTX_EAGER_TREE set in the environment.  `in` is consumed when a job is started.
+constexpr size_t kLazyTreeMinPrims = 1u << 18;
+std::shared_ptr<RefTreeJob> start_ref_tree_job(BuildInput& in, const std::vector<int>& devices);
+bool ref_tree_job_done(const RefTreeJob& job);
+// Waits for the job and moves the buffers of device slot `slot` (the position in `devices`) out of it.
+int ref_tree_job_take(RefTreeJob& job, int slot, RefTreeBuffers& out, std::string& err);
+
 struct HostScene {
   DScene<float> dev_f;
   DScene<double> dev_d;
@@ -84,6 +116,15 @@ struct HostScene {
   // prepare_scene(d).
   int upload_geometry(const rtx_scene_desc& d, std::string& err);
   int upload_tree(const rtx_scene_desc& d, const ScenePrep& prep, std::string& err);
+  // The second step for a scene whose reference-order tree is built in the background: counts, the eight-wide tree, no ranks yet.
+  int upload_tree_deferred(const rtx_scene_desc& d, std::shared_ptr<RefTreeJob> job, int slot, std::string& err);
+  std::shared_ptr<RefTreeJob> job;   // non-NULL until the tree has been adopted
+  int job_slot = -1;
+  bool tree_pending() const { return job != nullptr; }
+  // Takes the finished tree over (device pointers into dev_d / dev_f / dev_ref).  wait = false: only if the job is done.
+  // RTX_OK with tree_pending() still true means "not done yet".
+  int adopt_tree(bool wait, std::string& err);
+  int build_walk_tree(const uint8_t* d_dead, std::string& err);   // the eight-wide tree, on the current device
   int upload(const rtx_scene_desc& d, const ScenePrep& prep, std::string& err) {
     const int rc = upload_geometry(d, err);
     return rc != RTX_OK ? rc : upload_tree(d, prep, err);

@@ -92,7 +92,9 @@ template <class R> struct DScene {
   const DImage* images; const int32_t* emissive;   // indices of emissive spheres, ascending
   const DNodeRef* nodes; const DPrimRef* prims;     // double precision: the reference-order tree, walked nearest child first (left child of node i = i + 1); the reference's primitive order
   const DNode8* nodes8;                                // single-precision traversal layout: 64-byte units, node records and leaf records (NULL in the double scene and for scenes tested linearly)
-  const int32_t* rank;                                 // position of every bounded primitive (numbered as in DLeaf::ref) in the reference's leaf order
+  const int32_t* rank;                                 // position of every bounded primitive (numbered as in DLeaf::ref) in the reference's leaf order; NULL while the
+                                                       // reference-order tree is still being built on the host: exact ties in t then go by primitive number and are counted
+  unsigned long long* ties;                            // where such ties are counted (DCounters::ties of the render; set per launch)
   const DFlatRec* flat;                                // flat scenes only (single precision)
   float bb_lo[3], bb_scale[3];                         // the eight-wide tree's root box as a 128^3 grid: cell = (p - bb_lo) * bb_scale (ray sorting)
   float wt_anchor[3], wt_step[3];                      // the grid the node origins of the eight-wide tree lie on (DNode8::org)
@@ -139,7 +141,8 @@ template <class R> struct DPhotonNode { R p[3]; int32_t axis; };       // kd-tre
 template <class R> struct DPhotonData { R dir[3]; R power[3]; };
 template <class R> struct DPhotonBox { R lo[3]; R hi[3]; };
 
-struct DCounters { unsigned long long samples, closest, shadow, segments, nodes_visited, prims_tested; };
+// ties: exact ties in t between two bounded primitives that were decided WITHOUT the reference's leaf order (DScene::rank == NULL)
+struct DCounters { unsigned long long samples, closest, shadow, segments, nodes_visited, prims_tested, ties; };
 
 // One closest-hit answer in the layout of rtx_hit (include/rtx_hip.h).
 struct DHitOut {

@@ -207,6 +207,14 @@ struct rtx_ctx {
     int pipeline = 0;
     std::chrono::steady_clock::time_point wall0;
     rtx_stats st;   // what is known when the kernels are enqueued
+    // The render ran while the reference-order tree was still being built (HostScene::tree_pending): exact ties in t were decided
+    // by primitive number and counted.  If there was one, render_collect waits for the tree and renders the call again.
+    bool optimistic = false;
+    rtx_settings settings;
+    float* host_out = nullptr;
+    void* dev_out = nullptr;
+    hipStream_t user_stream = nullptr;
+    bool no_alloc = false, stream_as_given = false;
   } pending;
   // Multi-device context (rtx_create_multi): this is the context of the first listed device; `peers` are the contexts of the
   // others (owned), each with a host thread of its own (`workers`, same order); `gather` holds the peers' rows on this device
@@ -483,6 +491,16 @@ int rtx_destroy(rtx_ctx* c) {
 }
 
 static void settle(rtx_ctx* c);
+// The reference-order tree of a large scene is built in the background of rtx_upload_scene: whoever needs it on the device - the
+// double-precision kernels, the validation entry points, a frame with an exact tie in t - comes through here.
+static int need_tree(rtx_ctx* c) {
+  if (!c->scene.tree_pending()) return RTX_OK;
+  std::string err;
+  HIP_TRY(hipSetDevice(c->device));
+  const int rc = c->scene.adopt_tree(true, err);
+  if (rc != RTX_OK) { c->has_scene = false; return fail(rc, "reference-order tree: %s", err.c_str()); }
+  return RTX_OK;
+}
 static int upload_impl(rtx_ctx* c, const rtx_scene_desc* d) {
   if (!c || !d) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
   settle(c);
@@ -494,19 +512,6 @@ static int upload_impl(rtx_ctx* c, const rtx_scene_desc* d) {
   std::string err;
   int rc = validate_scene(*d, err);
   if (rc != RTX_OK) return fail(rc, "upload_scene: %s", err.c_str());
-  // The reference-order tree and what derives from it: built once, whatever the number of devices, on a host thread of its own
-  // (it makes no device call) while the scene's tables travel to the devices.
-  ScenePrep prep;
-  int prep_rc = RTX_OK;
-  std::string prep_err;
-  std::thread prep_thread([&] {
-    try { build_scene_prep(*d, prep);
-    } catch (const std::bad_alloc&) { prep_rc = RTX_ERR_OUT_OF_MEMORY; prep_err = "host allocation failed";
-    } catch (const std::exception& e) { prep_rc = RTX_ERR_HIP; prep_err = e.what(); }
-  });
-  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } join_on_every_path{prep_thread};
-  // every device takes its copy over its own host link and builds its eight-wide tree itself (the build is deterministic,
-  // so the trees are identical): one host thread per device
   std::vector<rtx_ctx*> all{c};
   all.insert(all.end(), c->peers.begin(), c->peers.end());
   std::vector<int> rcs(all.size(), RTX_OK);
@@ -519,12 +524,51 @@ static int upload_impl(rtx_ctx* c, const rtx_scene_desc* d) {
     } catch (const std::bad_alloc&) { rcs[k] = RTX_ERR_OUT_OF_MEMORY; errs[k] = "host allocation failed";
     } catch (const std::exception& e) { rcs[k] = RTX_ERR_HIP; errs[k] = e.what(); }
   };
+  // every device takes its copy over its own host link and builds its eight-wide tree itself (the build is deterministic,
+  // so the trees are identical): one host thread per device
   auto per_device = [&](auto&& body) {
     std::vector<std::thread> th;
     for (size_t k = 1; k < all.size(); ++k) th.emplace_back(body, k);
     body((size_t)0);
     for (std::thread& t : th) t.join();
   };
+  auto finish = [&]() -> int {
+    (void)hipSetDevice(c->device);
+    for (size_t k = 0; k < all.size(); ++k)
+      if (rcs[k] != RTX_OK) return fail(rcs[k], "upload_scene (device %d): %s", all[k]->device, errs[k].c_str());
+    for (rtx_ctx* x : all) x->has_scene = true;
+    return RTX_OK;
+  };
+  // A large scene without flat primitive boxes: the reference-order tree is built in the background (RefTreeJob) and this call
+  // returns as soon as the tables and the eight-wide trees are on the devices.
+  if (d->n_spheres + d->n_triangles + d->n_boxes >= kLazyTreeMinPrims && getenv("RTX_EAGER_TREE") == nullptr) {
+    const bool timing = getenv("RTX_TIMING") != nullptr;
+    BuildInput in;
+    make_build_input(*d, in);
+    if (timing) fprintf(stderr, "[rtx upload] %-28s %8.1f ms\n", "primitive boxes and keys", in.seconds * 1e3);
+    std::vector<int> devices;
+    for (rtx_ctx* x : all) devices.push_back(x->device);
+    std::shared_ptr<RefTreeJob> job = start_ref_tree_job(in, devices);
+    if (job) {
+      per_device([&](size_t k) {
+        guarded_step(k, [&] { return all[k]->scene.upload_geometry(*d, errs[k]); });
+        guarded_step(k, [&] { return all[k]->scene.upload_tree_deferred(*d, job, (int)k, errs[k]); });
+      });
+      return finish();
+    }
+    // (a primitive with a flat box: the tree is needed before the first ray, built below as for any other scene)
+  }
+  // The reference-order tree and what derives from it: built once, whatever the number of devices, on a host thread of its own
+  // (it makes no device call) while the scene's tables travel to the devices.
+  ScenePrep prep;
+  int prep_rc = RTX_OK;
+  std::string prep_err;
+  std::thread prep_thread([&] {
+    try { build_scene_prep(*d, prep);
+    } catch (const std::bad_alloc&) { prep_rc = RTX_ERR_OUT_OF_MEMORY; prep_err = "host allocation failed";
+    } catch (const std::exception& e) { prep_rc = RTX_ERR_HIP; prep_err = e.what(); }
+  });
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } join_on_every_path{prep_thread};
   per_device([&](size_t k) { guarded_step(k, [&] { return all[k]->scene.upload_geometry(*d, errs[k]); }); });
   prep_thread.join();
   if (prep_rc != RTX_OK) {
@@ -533,11 +577,7 @@ static int upload_impl(rtx_ctx* c, const rtx_scene_desc* d) {
     return fail(prep_rc, "upload_scene: %s", prep_err.c_str());
   }
   per_device([&](size_t k) { guarded_step(k, [&] { return all[k]->scene.upload_tree(*d, prep, errs[k]); }); });
-  (void)hipSetDevice(c->device);
-  for (size_t k = 0; k < all.size(); ++k)
-    if (rcs[k] != RTX_OK) return fail(rcs[k], "upload_scene (device %d): %s", all[k]->device, errs[k].c_str());
-  for (rtx_ctx* x : all) x->has_scene = true;
-  return RTX_OK;
+  return finish();
 }
 int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d) {
   const int rc = guarded([&] { return upload_impl(c, d); });
@@ -561,6 +601,7 @@ int rtx_set_camera(rtx_ctx* c, const rtx_camera* cam) {
 int rtx_get_bvh_info(rtx_ctx* c, rtx_bvh_info* out) {
   if (!c || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
   if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "no scene uploaded");
+  { const int rc = need_tree(c); if (rc != RTX_OK) return rc; }   // build_seconds is known when the tree is
   out->ref_nodes = c->scene.n_nodes; out->ref_prims = c->scene.n_prims;
   // the records the single-precision integrator walks (none for scenes small enough to be tested linearly)
   out->wide_nodes = (uint64_t)c->scene.wide.n_nodes;
@@ -576,6 +617,7 @@ int rtx_get_reference_bvh(rtx_ctx* c, rtx_bvh_node* nodes, size_t n_nodes, int32
   return guarded([&]() -> int {
     if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "no scene uploaded");
+    { const int rc = need_tree(c); if (rc != RTX_OK) return rc; }
     if (n_nodes != (size_t)c->scene.n_nodes || n_prims != (size_t)c->scene.n_prims)
       return fail(RTX_ERR_INVALID_ARGUMENT, "the tree has %d nodes and %d primitives (rtx_get_bvh_info), the buffers hold %zu and %zu", c->scene.n_nodes, c->scene.n_prims, n_nodes, n_prims);
     if ((n_nodes && !nodes) || (n_prims && (!prim_types || !prim_indices))) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL buffer");
@@ -589,6 +631,9 @@ int rtx_get_reference_bvh(rtx_ctx* c, rtx_bvh_node* nodes, size_t n_nodes, int32
   });
 }
 
+static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, bool no_alloc = false, bool bare = false,
+                          bool stream_as_given = false);
+
 // Second half of a render: waits for the kernels render_enqueue put on the stream and turns the counters and event times into
 // statistics.
 static int render_collect(rtx_ctx* c, rtx_stats* stats) {
@@ -600,6 +645,18 @@ static int render_collect(rtx_ctx* c, rtx_stats* stats) {
   HIP_TRY(hipStreamSynchronize(pd.stream));
   rtx_stats st = pd.st;
   const DCounters hc = *c->h_counters;
+  if (pd.optimistic && hc.ties > 0) {
+    // a tie in t was decided without the reference's leaf order: wait for that order and render the call again
+    const rtx_ctx::Pending again = pd;
+    const int trc = need_tree(c);
+    if (trc != RTX_OK) return trc;
+    const int rc = render_enqueue(c, &again.settings, again.host_out, again.dev_out, again.user_stream, again.no_alloc, false, again.stream_as_given);
+    if (rc != RTX_OK) return rc;
+    c->pending.wall0 = again.wall0;
+    c->pending.st.flags |= RTX_STAT_BEFORE_TREE | RTX_STAT_RENDERED_TWICE;
+    return render_collect(c, stats);
+  }
+  if (pd.optimistic) st.flags |= RTX_STAT_BEFORE_TREE;
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   st.samples = hc.samples; st.rays_closest = hc.closest; st.rays_shadow = hc.shadow; st.segments = hc.segments;
@@ -624,8 +681,8 @@ static void settle(rtx_ctx* c) {
 // counters to pinned host memory) on the stream; render_collect finishes it.  `no_alloc`: the render may not allocate
 // (rtx_render_device_noalloc): its chunk sums and counters go to the device's scratch array, and whatever would need another
 // buffer is refused; with `bare` as well it records nothing but kernels (no event, no copy) and leaves nothing to collect.
-static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, bool no_alloc = false, bool bare = false,
-                          bool stream_as_given = false /* NULL is HIP's default stream, not the context's own */) {
+static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, bool no_alloc, bool bare,
+                          bool stream_as_given /* NULL is HIP's default stream, not the context's own */) {
   if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
   settle(c);
   if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "render before upload_scene");
@@ -671,6 +728,8 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     rtx_ctx::Pending& pd = c->pending;
     pd.active = true; pd.stream = stream; pd.photon_map_reused = reused; pd.wavefront = pipeline_used == RTX_PIPELINE_WAVEFRONT; pd.f64 = is_f64;
     pd.pipeline = pipeline_used; pd.wall0 = wall0; pd.st = st;
+    pd.optimistic = false; pd.settings = *s; pd.host_out = host_out; pd.dev_out = dev_out; pd.user_stream = user_stream; pd.no_alloc = no_alloc;
+    pd.stream_as_given = stream_as_given;
   };
   if (npix == 0) {   // a shard without rows: nothing to launch, empty statistics
     if (bare) return RTX_OK;
@@ -697,6 +756,19 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
   if (pipeline == RTX_PIPELINE_WAVEFRONT && whitted) return fail(RTX_ERR_UNSUPPORTED, "the Whitted mode is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && mnee) return fail(RTX_ERR_UNSUPPORTED, "use_mnee is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && f64) return fail(RTX_ERR_UNSUPPORTED, "the wavefront pipeline is single precision only");
+
+  // A scene whose reference-order tree is still being built: the plain single-precision path tracer renders without it (ties are
+  // counted, render_collect renders again if there was one); whatever else needs it waits here.
+  bool optimistic = false;
+  if (c->scene.tree_pending()) {
+    std::string terr;
+    int trc = c->scene.adopt_tree(false, terr);   // takes it over if it has arrived meanwhile
+    if (trc == RTX_OK && c->scene.tree_pending()) {
+      if (f64 || whitted || bdpt || photon || mnee || bare) trc = c->scene.adopt_tree(true, terr);
+      else optimistic = true;
+    }
+    if (trc != RTX_OK) { c->has_scene = false; return fail(trc, "reference-order tree: %s", terr.c_str()); }
+  }
 
   float* d_film = (float*)dev_out;
   void* partial_ptr = nullptr;
@@ -756,7 +828,8 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     const int blocks_per_cu = stack ? 3 : 6;
     L.grid = (int)std::min<unsigned long long>((items + kBlock - 1) / kBlock, (unsigned long long)c->n_cus * blocks_per_cu);
     int lrc;
-    const DScene<float>& scf = c->scene.dev_f;
+    DScene<float> scf = c->scene.dev_f;
+    scf.ties = &counters_ptr->ties;
     if (photon) {   // the photon pass comes first (ref: engine/renderer.cpp:344-372); its rays are counted as closest-hit queries
       // the photon kernel is the tree-walking instance whatever the render kernel is (a flat scene of 13 to 16 spheres walks
       // its tree there), so its traversal stacks are sized from the scene alone
@@ -807,7 +880,9 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     std::string err;
     if (stack_words(c, false) * kBlock * sizeof(int) > c->lds_per_block)
       return fail(RTX_ERR_UNSUPPORTED, "this scene's traversal stacks need %zu bytes of LDS per workgroup, the device gives %zu", stack_words(c, false) * kBlock * sizeof(int), c->lds_per_block);
-    int rc = wavefront_render(c->wf, c->scene.dev_f, c->cam_f, P, d_film, counters_ptr, c->n_cus, c->scene.fused_mode(false), (int)stack_words(c, false), stream, st.kernel_launches, err);
+    DScene<float> scw = c->scene.dev_f;
+    scw.ties = &counters_ptr->ties;
+    int rc = wavefront_render(c->wf, scw, c->cam_f, P, d_film, counters_ptr, c->n_cus, c->scene.fused_mode(false), (int)stack_words(c, false), stream, st.kernel_launches, err);
     if (rc != RTX_OK) return fail(rc, "wavefront: %s", err.c_str());
     HIP_TRY(hipEventRecord(c->evm, stream));
   }
@@ -817,6 +892,7 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
   HIP_TRY(hipMemcpyAsync(c->h_counters, counters_ptr, sizeof(DCounters), hipMemcpyDeviceToHost, stream));
   if (host_out) HIP_TRY(hipMemcpyAsync(host_out, d_film, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
   arm(pipeline, f64, photon_map_reused);
+  c->pending.optimistic = optimistic;
   return RTX_OK;
 }
 
@@ -972,6 +1048,7 @@ static int render_multi(rtx_ctx* c, const rtx_settings* s, float* host_out, void
       // the devices run side by side: the call takes as long as the slowest
       t.seconds_render = std::max(t.seconds_render, a.seconds_render); t.seconds_main_kernel = std::max(t.seconds_main_kernel, a.seconds_main_kernel);
       t.seconds_photon_pass = std::max(t.seconds_photon_pass, a.seconds_photon_pass); t.seconds_extend = std::max(t.seconds_extend, a.seconds_extend);
+      t.flags |= a.flags;
       if (t.pipeline_used == 0) { t.pipeline_used = a.pipeline_used; t.precision_used = a.precision_used; }
     }
     t.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
@@ -1076,6 +1153,7 @@ static int trace_impl(rtx_ctx* c, const double* rays8, size_t n, rtx_hit* out, i
   if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "trace before upload_scene");
   if (n == 0) return RTX_OK;
   settle(c);
+  { const int rc = need_tree(c); if (rc != RTX_OK) return rc; }
   static_assert(sizeof(DHitOut) == sizeof(rtx_hit), "hit layouts must agree");
   HIP_TRY(hipSetDevice(c->device));
   if (!c->rays.ensure(n * 8 * sizeof(double)) || !c->hits.ensure(n * sizeof(DHitOut))) return fail(RTX_ERR_OUT_OF_MEMORY, "ray batch of %zu", n);

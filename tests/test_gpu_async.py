@@ -123,3 +123,68 @@ def test_rccl_gather_of_a_multi_device_context(pkg, load_scene):
         twice.set_camera(sd.camera(96, 54))
         twice.set_settings(sd.settings(**kw))
         assert np.array_equal(twice.render(), whole)
+
+
+def _big_soup(pkg, load_scene, n, duplicates=0):
+    """cornell_box_quad + n small triangles (enough for rtx_upload_scene to build the reference-order tree in the background);
+    `duplicates` of them occur twice, the copy with another material: every hit on such a pair is an exact tie in t."""
+    import copy
+    sd = copy.copy(load_scene("cornell_box_quad"))
+    sd._keep = []
+    soup = pkg.synthetic.triangle_soup(n, seed=9, extent=2.2, size=0.08, n_materials=5)
+    for k in ("v0", "v1", "v2"):
+        soup[k] += (0, 2.5, -2.5)
+    if duplicates:
+        twin = soup[:duplicates].copy()
+        twin["material_id"] = (twin["material_id"] + 2) % 5
+        soup = np.concatenate([soup, twin])
+    sd.triangle_array = soup
+    return sd
+
+
+@pytest.mark.parametrize("pipeline", ["queues", "fused"])
+def test_render_before_the_reference_order_tree_arrives(pipeline, pkg, load_scene):
+    abi = pkg.abi
+    kw = dict(width=160, height=90, samples_per_pixel=4, max_depth=6, seed=8,
+              pipeline=abi.PIPELINE_WAVEFRONT if pipeline == "queues" else abi.PIPELINE_FUSED)
+
+    def render(sd, env, after=None):
+        old = {k: os.environ.get(k) for k in ("RTX_EAGER_TREE", "RTX_TREE_DELAY_MS")}
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            with pkg.renderer.HipPathTracer(0) as pt:
+                pt.upload_scene(sd)
+                pt.set_camera(sd.camera(kw["width"], kw["height"]))
+                pt.set_settings(sd.settings(**kw))
+                film = pt.render().copy()
+                flags = pt.last_stats.flags
+                more = after(pt) if after else None
+                return film, flags, more
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+
+    plain = _big_soup(pkg, load_scene, 300_000)
+    want, flags, _ = render(plain, {"RTX_EAGER_TREE": "1"})
+    assert flags == 0
+
+    def second(pt):
+        info = pt.bvh_info()                 # waits for the tree
+        assert info.ref_prims == 300_000 and info.build_seconds > 0
+        film = pt.render().copy()
+        return film, pt.last_stats.flags
+    got, flags, (again, flags2) = render(plain, {"RTX_TREE_DELAY_MS": "1500"}, second)
+    assert flags == abi.STAT_BEFORE_TREE                                 # rendered without the tree, and no tie occurred
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert flags2 == 0 and np.array_equal(again.view(np.uint32), want.view(np.uint32))
+
+    twins = _big_soup(pkg, load_scene, 300_000, duplicates=60_000)
+    want2, flags, _ = render(twins, {"RTX_EAGER_TREE": "1"})
+    assert flags == 0 and not np.array_equal(want2, want)
+    got2, flags, _ = render(twins, {"RTX_TREE_DELAY_MS": "1500"})
+    assert flags == abi.STAT_BEFORE_TREE | abi.STAT_RENDERED_TWICE      # ties: the frame was rendered again with the reference's order
+    assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
