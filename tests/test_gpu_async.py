@@ -174,7 +174,7 @@ def test_render_before_the_reference_order_tree_arrives(pipeline, pkg, load_scen
 
     def second(pt):
         info = pt.bvh_info()                 # waits for the tree
-        assert info.ref_prims == 300_000 and info.build_seconds > 0
+        assert info.ref_prims == 300_002 and info.build_seconds > 0   # the soup and the two spheres of the box
         film = pt.render().copy()
         return film, pt.last_stats.flags
     got, flags, (again, flags2) = render(plain, {"RTX_TREE_DELAY_MS": "1500"}, second)
