@@ -62,6 +62,9 @@ using namespace rtx;
 // array's name is only a host-side handle, so the device address is looked up once per device (scratch_pointer) and that
 // pointer, never the name, is what kernels and fills receive.
 // ------------------------------------------------------------------------------------------
+// Samples and work items (pixel, sample chunk) a lane of a fused launch handles at least, which sizes the grid (see the launch in
+// render_enqueue).
+constexpr unsigned long long kFusedSamplesPerLane = 32, kFusedMinItemsPerLane = 3;
 constexpr size_t kScratchBytes = 64ull << 20;
 constexpr size_t kScratchHeader = 256;   // the counters, ahead of the chunk sums
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
@@ -825,8 +828,27 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     if (L.lds_bytes > c->lds_per_block)
       return fail(RTX_ERR_UNSUPPORTED, "this scene's traversal stacks need %zu bytes of LDS per workgroup, the device gives %zu", L.lds_bytes, c->lds_per_block);
     // Persistent grid: enough workgroups to fill every CU at the kernel's occupancy, no more.
+    // Grid: at least what fills every CU at the kernel's occupancy; beyond that, so many workgroups that a lane gets about
+    // kFusedSamplesPerLane samples (and at least kFusedMinItemsPerLane work items).  A lane's items are fixed by its index
+    // (item = lane + k * lanes), so a workgroup keeps returning to the same few strips of the image, and strips through glass and
+    // mirrors cost several times what bare walls cost: with exactly the resident number of workgroups the slow ones ran on alone at
+    // the end of a launch.  Many short workgroups let the dispatcher even that out; too short ones (a dozen samples per lane) lose
+    // again to the spread inside a wave and to the per-workgroup set-up.  Measured, ms per render, resident grid -> best (samples
+    // per lane at the best): 1080p Cornell box 1024 spp 202.5 -> 168.4 (192; 128: 169.0, 384: 169.7); cornell_box_quad +
+    // caustics_test 800 x 800 x 128 16.8 -> 14.5 (24; 48: 14.8); Cornell box 64 spp 15.5 -> 13.3 (24; 96: 14.2), 16 spp 4.94 -> 4.49
+    // (12; 24: 4.65, 6: 5.44); double precision 32 spp 34.0 -> 32.0 (48); manifold NEE 16 spp 338.7 -> 317.2 (24); environment_demo
+    // 4K 256 spp 220.5 -> 186.6.  Whitted (uniform cost per pixel: 22.2 -> 22.3 at best) keeps the resident grid, as do BDPT and
+    // PathPhoton, which size per-lane stores by the grid.  The film does not depend on the grid.
     const int blocks_per_cu = stack ? 3 : 6;
-    L.grid = (int)std::min<unsigned long long>((items + kBlock - 1) / kBlock, (unsigned long long)c->n_cus * blocks_per_cu);
+    const unsigned long long one_item_each = (items + kBlock - 1) / kBlock, resident = (unsigned long long)c->n_cus * blocks_per_cu;
+    unsigned long long per_lane = 0ull;   // 0 = the resident grid
+    if (!bdpt && !photon && !whitted) {
+      per_lane = std::max<unsigned long long>(kFusedMinItemsPerLane, (kFusedSamplesPerLane + (unsigned long long)P.chunk_spp - 1ull) / (unsigned long long)P.chunk_spp);
+      if (const char* e = std::getenv("RTX_ITEMS_PER_LANE")) { const long v = std::atol(e); if (v >= 0 && v <= 4096) per_lane = (unsigned long long)v; }   // experiments
+    }
+    unsigned long long grid = std::min(one_item_each, resident);
+    if (per_lane) grid = std::max(grid, (items + kBlock * per_lane - 1) / (kBlock * per_lane));
+    L.grid = (int)grid;
     int lrc;
     DScene<float> scf = c->scene.dev_f;
     scf.ties = &counters_ptr->ties;
