@@ -1050,10 +1050,12 @@ RTX_DEV bool flat_disk_t(const DDisk<float>& dl, const Ray<float>& r, float t_mi
 }
 
 // Closest hit of a flat scene: every primitive is tested without branches; only the distance and the
-// position of the winner in the test order are carried along, its shading record is fetched at the end.
-RTX_DEV bool flat_closest(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_max, Hit<float>& h) {
-  float best = t_max;
-  int k = -1, n = 0;
+// position of the winner in the test order are carried along (flat_closest_tk), its shading record is fetched at the end
+// (flat_hit_from).
+RTX_DEV void flat_closest_tk(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_max, float& best, int& k) {
+  best = t_max;
+  k = -1;
+  int n = 0;
   const float a = len2(r.d), inv_a = rcp_(a);
   float t;
   for (int i = 0; i < sc.n_prims; ++i, ++n) {   // all spheres in flat scenes, in reference leaf order
@@ -1072,6 +1074,8 @@ RTX_DEV bool flat_closest(const DScene<float>& sc, const Ray<float>& r, float t_
     const bool ok = flat_disk_t(sc.disks[i], r, t_min, best, t);
     best = ok ? t : best; k = ok ? n : k;
   }
+}
+RTX_DEV bool flat_hit_from(const DScene<float>& sc, const Ray<float>& r, float best, int k, Hit<float>& h) {
   if (k < 0) return false;
   const DFlatRec rec = sc.flat[k];
   h.t = best; h.type = rec.type; h.idx = rec.idx; h.mat = rec.mat; h.u = 0.f; h.v = 0.f;
@@ -1080,6 +1084,12 @@ RTX_DEV bool flat_closest(const DScene<float>& sc, const Ray<float>& r, float t_
   V3<float> on = rec.w != 0.f ? (h.p - abc) * rec.w : abc;
   face_normal(h, r, on);
   return true;
+}
+RTX_DEV bool flat_closest(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_max, Hit<float>& h) {
+  float best;
+  int k;
+  flat_closest_tk(sc, r, t_min, t_max, best, k);
+  return flat_hit_from(sc, r, best, k, h);
 }
 
 // UNIT: the caller's direction has unit length (the light-sample rays of the path tracer), so |d|^2 is taken as 1.

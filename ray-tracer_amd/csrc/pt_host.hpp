@@ -152,6 +152,7 @@ struct FusedLaunch {
   size_t lds_bytes;     // dynamic LDS per workgroup
   int stack_first_int;  // offset (in ints) of the traversal stacks inside the dynamic LDS
   int integ = INTEG_PATH;  // INTEG_*: path tracing, path tracing with MNEE (double precision only), Whitted (TREE_UV instances only)
+  int regroup = 0;         // experiment (RTX_FUSED_REGROUP): > 0 launches the material-coherent variant of the lean flat path tracer; lanes trade places when a wave has at least this many lanes outside its majority class
 };
 // PathPhoton photon pass (pt_photon.hpp): `out` = 10 planes of n_photons values (position, -direction, power, valid)
 void launch_photon_trace(const DScene<float>& sc, const DRenderParams& P, const DPhotonLight* lights, int n_lights, const int32_t* targets, int n_targets,
@@ -185,6 +186,7 @@ void launch_zero_words(uint32_t* p, unsigned n, hipStream_t stream);   // p[0 ..
 struct WavefrontPool {
   DeviceBuffer state, queues, control, sort_tmp;
   bool sort_rays = false;   // this render sorts its ray queues before the traversal kernels take them
+  bool sort_materials = false;   // this render orders the shade kernel's entries by material class (experiment)
   // HIP events around every launch of the closest-hit traversal kernel of the last render (pairs: before, after)
   std::vector<hipEvent_t> events;
   size_t events_used = 0;

@@ -213,6 +213,155 @@ __global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same path tracer with MATERIAL-COHERENT waves (experiment, RTX_FUSED_REGROUP=1; flat scenes, plain path tracing).
+// After the closest-hit query of a trip every lane knows what its vertex needs next: a Lambertian vertex (light sample, shadow
+// query, cosine scatter), a specular one (mirror / glass), the end of its path (miss, light: the next sample starts), or
+// nothing (no work left).  The 256 lanes of the workgroup then trade places through LDS - a stable partition by that class, the
+// whole lane state moves: path, hit, work item - so that a wave holds one class where the counts allow it, and the shading code of
+// the other classes is skipped by whole waves instead of being paid under a mask.  Which lane computes a path changes, what is
+// computed does not: films equal render_fused_kernel's to the rounding of a separately compiled kernel.
+// Measured on the 1080p Cornell box (profiles/r03_c2_regroup/): the exchange costs more than the skipped code saves; the
+// plain kernel stays the one that is launched.
+// ------------------------------------------------------------------------------------------
+constexpr int kRegroupWords = 25;
+template <int LEAN>
+__global__ __launch_bounds__(kBlock, RTX_LEAN_MIN_WAVES) void render_fused_regroup_kernel(DScene<float> sc, DCamera<float> cam, DRenderParams P, float* __restrict__ partial,
+                                                                                         DCounters* __restrict__ counters, int regroup_min_minority) {
+  using R = float;
+  if constexpr ((LEAN & 1) != 0) { sc.env.valid = 0; sc.env.importance = 0; }
+  if constexpr ((LEAN & 2) != 0) { sc.n_points = 0; sc.n_disks = 0; }
+  if constexpr ((LEAN & 4) != 0) { sc.n_quads = 0; }
+  if constexpr ((LEAN & 8) != 0) { P.use_nee = 1; P.use_mis = 1; }
+  if constexpr ((LEAN & 16) != 0) { P.rng = RNG_PCG4D; }
+  if constexpr ((LEAN & 64) != 0) { sc.n_emissive = 0; }
+  const DMaterial<R>* mats = stage_materials(sc);
+  __shared__ uint32_t xch[kRegroupWords][kBlock];
+  __shared__ uint32_t cnt[kBlock / 64][4];
+  const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
+  const uint32_t n_items = npix * (uint32_t)P.n_chunks;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  uint32_t next = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  uint32_t w_steps = 0, w_shadow = 0, w_shaded = 0, w_samples = 0;
+  PathState<R> ps;
+  ps.ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}}; ps.thr = {0.f, 0.f, 0.f}; ps.acc = {0.f, 0.f, 0.f}; ps.bsdf_pdf = 0.f;
+  ps.bounce_flags = 0;
+  V3<R> sum = {R(0), R(0), R(0)};
+  uint32_t cur = 0, xy = 0, pixel = 0;
+  int s = 0, s_end = 0;
+  auto fetch = [&]() -> bool {
+    if (next >= n_items) return false;
+    cur = next;
+    next += stride;
+    uint32_t chunk = cur / npix;
+    uint32_t pix = cur - chunk * npix;
+    uint32_t row_local = pix / (uint32_t)P.width;
+    uint32_t x = pix - row_local * (uint32_t)P.width;
+    uint32_t y = (uint32_t)P.shard_index + row_local * (uint32_t)P.shard_count;
+    xy = (y << 16) | x;
+    pixel = y * (uint32_t)P.width + x;
+    s = (int)chunk * P.chunk_spp;
+    s_end = s + P.chunk_spp < P.spp ? s + P.chunk_spp : P.spp;
+    sum = {R(0), R(0), R(0)};
+    return s < s_end;
+  };
+  bool active = fetch();
+  if (active) { PathKey key = {pixel, P.seed, (uint32_t)s++, (uint32_t)P.rng}; path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key); }
+  w_samples += (uint32_t)__popcll(__ballot(active));
+  for (;;) {
+    // 1. closest hit: the same work for every lane with a path
+    float t = 0.f;
+    int k = -1;
+    if (active) flat_closest_tk(sc, ps.ray, 0.001f, 1e9f, t, k);
+    w_steps += (uint32_t)__popcll(__ballot(active));
+    // 2. what the vertex needs: 0 Lambertian, 1 specular, 2 the path ends here (miss, light), 3 no path
+    int cls = 3;
+    if (active) {
+      cls = 2;
+      if (k >= 0) {
+        const int mat = sc.flat[k].mat;
+        if (mat >= 0) cls = mats[mat].type == MAT_LAMBERTIAN ? 0 : 1;
+      }
+    }
+    // 3. stable partition of the workgroup's lanes by class
+    const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+    if (lane == 0) { cnt[wave][0] = (uint32_t)__popcll(m0); cnt[wave][1] = (uint32_t)__popcll(m1); cnt[wave][2] = (uint32_t)__popcll(m2); cnt[wave][3] = (uint32_t)__popcll(m3); }
+    __syncthreads();
+    uint32_t tot[4] = {0u, 0u, 0u, 0u}, before = 0u;   // lanes of my class in earlier waves
+    int mixed_waves = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+      const uint32_t c0 = cnt[w][0], c1 = cnt[w][1], c2 = cnt[w][2], c3 = cnt[w][3];
+      tot[0] += c0; tot[1] += c1; tot[2] += c2; tot[3] += c3;
+      if (w < wave) before += cls == 0 ? c0 : cls == 1 ? c1 : cls == 2 ? c2 : c3;
+      const uint32_t major = c0 > c1 ? (c0 > c2 ? (c0 > c3 ? c0 : c3) : (c2 > c3 ? c2 : c3)) : (c1 > c2 ? (c1 > c3 ? c1 : c3) : (c2 > c3 ? c2 : c3));
+      mixed_waves += (64u - major) >= (uint32_t)regroup_min_minority ? 1 : 0;
+    }
+    if (tot[3] == (uint32_t)kBlock) break;   // no lane of the workgroup has a path left (the same answer in every lane)
+    if (mixed_waves > 0) {                   // (the same in every lane of the workgroup)
+      const unsigned long long mine = cls == 0 ? m0 : cls == 1 ? m1 : cls == 2 ? m2 : m3;
+      const uint32_t base = cls == 0 ? 0u : cls == 1 ? tot[0] : cls == 2 ? tot[0] + tot[1] : tot[0] + tot[1] + tot[2];
+      const uint32_t dest = base + before + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+      const uint32_t out[kRegroupWords] = {__float_as_uint(ps.ray.o.x), __float_as_uint(ps.ray.o.y), __float_as_uint(ps.ray.o.z), __float_as_uint(ps.ray.d.x),
+                                           __float_as_uint(ps.ray.d.y), __float_as_uint(ps.ray.d.z), __float_as_uint(ps.thr.x), __float_as_uint(ps.thr.y),
+                                           __float_as_uint(ps.thr.z), __float_as_uint(ps.acc.x), __float_as_uint(ps.acc.y), __float_as_uint(ps.acc.z),
+                                           __float_as_uint(ps.bsdf_pdf), ps.bounce_flags, __float_as_uint(t), (uint32_t)k, __float_as_uint(sum.x),
+                                           __float_as_uint(sum.y), __float_as_uint(sum.z), cur, xy, (uint32_t)s, (uint32_t)s_end, next, (uint32_t)cls};
+#pragma unroll
+      for (int i = 0; i < kRegroupWords; ++i) xch[i][dest] = out[i];
+      __syncthreads();
+      uint32_t in[kRegroupWords];
+#pragma unroll
+      for (int i = 0; i < kRegroupWords; ++i) in[i] = xch[i][threadIdx.x];
+      ps.ray.o = {__uint_as_float(in[0]), __uint_as_float(in[1]), __uint_as_float(in[2])};
+      ps.ray.d = {__uint_as_float(in[3]), __uint_as_float(in[4]), __uint_as_float(in[5])};
+      ps.thr = {__uint_as_float(in[6]), __uint_as_float(in[7]), __uint_as_float(in[8])};
+      ps.acc = {__uint_as_float(in[9]), __uint_as_float(in[10]), __uint_as_float(in[11])};
+      ps.bsdf_pdf = __uint_as_float(in[12]); ps.bounce_flags = in[13];
+      t = __uint_as_float(in[14]); k = (int)in[15];
+      sum = {__uint_as_float(in[16]), __uint_as_float(in[17]), __uint_as_float(in[18])};
+      cur = in[19]; xy = in[20]; s = (int)in[21]; s_end = (int)in[22]; next = in[23]; cls = (int)in[24];
+      pixel = (xy >> 16) * (uint32_t)P.width + (xy & 0xffffu);
+      active = cls != 3;
+    }
+    __syncthreads();   // cnt and xch are free for the next trip
+    // 4. shade, as path_step does after its trace
+    uint32_t did = 0;
+    if (active) {
+      PathKey key = {pixel, P.seed, (uint32_t)(s - 1), (uint32_t)P.rng};
+      Hit<R> rec;
+      const bool hit = flat_hit_from(sc, ps.ray, t, k, rec);
+      did = path_vertex<R, false>(ps, hit, rec, sc, mats, P, key, [&](const Ray<R>& sr, R t_max, V3<R> contrib) {
+        if (!flat_occluded<true>(sc, sr, 0.001f, t_max)) ps.acc = ps.acc + contrib;
+      });
+    }
+    w_shadow += (uint32_t)__popcll(__ballot((did & STEP_SHADOW) != 0));
+    w_shaded += (uint32_t)__popcll(__ballot((did & STEP_SHADED) != 0));
+    bool started = false;
+    if (active && !(ps.bounce_flags & F_ALIVE)) {
+      sum = sum + ps.acc;
+      if (s == s_end) {
+        R* o = partial + (size_t)cur * 3u;
+        o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+        active = fetch();
+      }
+      if (active) {
+        PathKey key = {pixel, P.seed, (uint32_t)s++, (uint32_t)P.rng};
+        path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key);
+        started = true;
+      }
+    }
+    w_samples += (uint32_t)__popcll(__ballot(started));
+  }
+  if (lane == 0) {
+    atomicAdd(&counters->samples, (unsigned long long)w_samples);
+    atomicAdd(&counters->closest, (unsigned long long)w_steps);
+    atomicAdd(&counters->shadow, (unsigned long long)w_shadow);
+    atomicAdd(&counters->segments, (unsigned long long)w_shaded);
+  }
+}
+
 // film[pixel] = (sum of the pixel's chunk sums, in chunk order) * (1 / spp)
 // ref: engine/renderer.cpp:447 (pixel_color * (1.0 / samples_per_pixel))
 template <class R>

@@ -245,6 +245,29 @@ __global__ __launch_bounds__(256) void wf_sort_keys(DScene<float> sc, WfArrays A
   A.key_in[i] = key; A.order_in[i] = entry;
 }
 
+// Material queues (experiment, RTX_MATERIAL_SORT=1): the ray queue wf_shade is about to take, ordered by what its vertices need -
+// 0 Lambertian, 1 metal, 2 dielectric, 3 no bounded hit (a plane, a light or nothing: wf_shade finds out) - so that the waves of the
+// shade kernel run one material branch each.  The key of an entry comes from its stored hit (one fetch of the primitive's
+// material index, one of the material's type); entries past the queue's end sort last.
+constexpr unsigned kMaterialKeyBits = 3;
+__global__ __launch_bounds__(256) void wf_material_keys(DScene<float> sc, WfArrays A, const WfControl* __restrict__ ctl, int q, int nq, uint32_t bound) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bound) return;
+  const uint32_t n = ctl->n_q_[nq].v;
+  uint32_t key = 7u, entry = 0u;
+  if (i < n) {
+    entry = A.q[q][i];
+    const int id = A.hit_id[entry];
+    key = 3u;
+    if (id >= 0) {
+      const int type = id >> kIdBits, idx = id & kIdMask;
+      const int mat = type == PRIM_SPHERE ? sc.spheres[idx].mat : type == PRIM_TRIANGLE ? sc.tris[idx].mat : type == PRIM_BOX ? sc.boxes[idx].mat : -1;
+      if (mat >= 0) key = (uint32_t)sc.mats[mat].type;
+    }
+  }
+  A.key_in[i] = key; A.order_in[i] = entry;
+}
+
 // Both traversal kernels are persistent: a launch holds as many lanes as the chip keeps
 // resident, every lane walks one ray at a time in resumable steps and takes its next queue
 // entry (grid-stride) when its ray is finished, so a wave is not held back by its longest
@@ -407,7 +430,7 @@ constexpr uint32_t kShadowToItem = 0x80000000u;
 
 template <int MODE, bool LDS_MATS, bool NMAP = false>
 __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCamera<float> cam, DRenderParams P, WfArrays A, WfControl* ctl, WfTurn turn,
-                                                   float* __restrict__ partial, WfStatBank* banks) {
+                                                   float* __restrict__ partial, WfStatBank* banks, const uint32_t* __restrict__ order /* the queue's entries in the order to take them, or NULL = as queued */) {
   const DMaterial<float>* mats = sc.mats;
   if constexpr (LDS_MATS) mats = stage_materials(sc);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -425,7 +448,7 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
   uint32_t slot = 0, sh_target = 0;
   bool live = false, started = false;   // the slot has a ray to trace next; it began a new sample
   if (valid) {
-  slot = A.q[turn.q_in][i];
+  slot = order ? order[i] : A.q[turn.q_in][i];
   sh_target = slot;
   PathState<float> ps;
   ps.ray.o = {A.ray[0][slot], A.ray[1][slot], A.ray[2][slot]};
@@ -577,11 +600,19 @@ template <int MODE> void launch_turn_kernels(const DScene<float>& sc, const DCam
     ++launches;
   } else {
     q_out = turn->q_out; n_out = turn->n_out;
+    const uint32_t* shade_order = nullptr;
+    if (pool.sort_materials) {   // experiment: material queues
+      hipLaunchKernelGGL(wf_material_keys, dim3((bound + 255) / 256), dim3(256), 0, stream, sc, A, ctl, turn->q_in, turn->n_in, bound);
+      size_t bytes = pool.sort_tmp.cap;
+      (void)rocprim::radix_sort_pairs(pool.sort_tmp.ptr, bytes, A.key_in, A.key_out, A.order_in, A.order_out, (size_t)bound, 0u, kMaterialKeyBits, stream);
+      launches += 2;
+      shade_order = A.order_out;
+    }
     if (MODE == MODE_TREE_UV && sc.n_nmaps > 0) {   // the instances that apply normal maps
-      if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true, MODE == MODE_TREE_UV>), g, bs, mat_lds, stream, sc, cam, P, A, ctl, *turn, partial, banks);
-      else hipLaunchKernelGGL((wf_shade<MODE, false, MODE == MODE_TREE_UV>), g, bs, 0, stream, sc, cam, P, A, ctl, *turn, partial, banks);
-    } else if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, cam, P, A, ctl, *turn, partial, banks);
-    else hipLaunchKernelGGL((wf_shade<MODE, false>), g, bs, 0, stream, sc, cam, P, A, ctl, *turn, partial, banks);
+      if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true, MODE == MODE_TREE_UV>), g, bs, mat_lds, stream, sc, cam, P, A, ctl, *turn, partial, banks, shade_order);
+      else hipLaunchKernelGGL((wf_shade<MODE, false, MODE == MODE_TREE_UV>), g, bs, 0, stream, sc, cam, P, A, ctl, *turn, partial, banks, shade_order);
+    } else if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, cam, P, A, ctl, *turn, partial, banks, shade_order);
+    else hipLaunchKernelGGL((wf_shade<MODE, false>), g, bs, 0, stream, sc, cam, P, A, ctl, *turn, partial, banks, shade_order);
     if (sorted) sort_queue(0, turn->sh, 1);
     hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, turn->sh, partial, stack_levels, sorted ? A.order_out : nullptr);
     launches += 2;
@@ -653,7 +684,12 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   // triangle soup, the closest-hit kernel took the same time (it is bound by vector-ALU issue, not by the lines it fetches) and the
   // sorts added 68 ms to a 608 ms frame.  RTX_RAY_SORT=1 switches it on (experiments only; films do not depend on it).
   pool.sort_rays = sc.n_nodes8 > 0 && mode != MODE_FLAT && getenv("RTX_RAY_SORT") != nullptr;
-  if (pool.sort_rays) {
+  // Material queues (the shade kernel takes its entries ordered by material class) are off by default as well: measured on the
+  // same frame, the keys and the sort cost several times what the shade kernel gains.  RTX_MATERIAL_SORT=1 switches them on
+  // (experiments only; films do not depend on it).  The ray sort and the material sort share the key / order arrays: the shade
+  // kernel's order is used up before the ray sort of the same turn writes them again.
+  pool.sort_materials = getenv("RTX_MATERIAL_SORT") != nullptr;
+  if (pool.sort_rays || pool.sort_materials) {
     size_t bytes = 0;
     if (rocprim::radix_sort_pairs(nullptr, bytes, A.key_in, A.key_out, A.order_in, A.order_out, (size_t)n_slots, 0u, kSortKeyBits, stream) != hipSuccess ||
         !pool.sort_tmp.ensure(bytes)) { err = "pool allocation (ray sort)"; return RTX_ERR_OUT_OF_MEMORY; }

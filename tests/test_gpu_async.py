@@ -82,13 +82,17 @@ def _queue_film(pkg, sd, env, **kw):
                 os.environ[k] = v
 
 
-def test_a_smaller_pool_gives_the_same_film(pkg, load_scene):
+def test_a_smaller_pool_and_material_queues_give_the_same_film(pkg, load_scene):
     """The queue pipeline halves its pool of path slots when the device cannot give the full one (RTX_POOL_MULT caps the first try):
     slots are reused more often, the film is the same."""
     sd = soup_scene(pkg, load_scene, n=60000)
     kw = dict(width=640, height=360, samples_per_pixel=16, max_depth=6, seed=2)
     film, st = _queue_film(pkg, sd, {"RTX_POOL_MULT": "1"}, **kw)
     want, st0 = _queue_film(pkg, sd, {}, **kw)
+    assert np.array_equal(film.view(np.uint32), want.view(np.uint32))
+    assert (st.samples, st.rays_closest, st.rays_shadow, st.segments) == (st0.samples, st0.rays_closest, st0.rays_shadow, st0.segments)
+    # material queues (an experiment kept for its measurement): the shade kernel takes its entries ordered by material class
+    film, st = _queue_film(pkg, sd, {"RTX_MATERIAL_SORT": "1"}, **kw)
     assert np.array_equal(film.view(np.uint32), want.view(np.uint32))
     assert (st.samples, st.rays_closest, st.rays_shadow, st.segments) == (st0.samples, st0.rays_closest, st0.rays_shadow, st0.segments)
 
@@ -188,3 +192,29 @@ def test_render_before_the_reference_order_tree_arrives(pipeline, pkg, load_scen
     got2, flags, _ = render(twins, {"RTX_TREE_DELAY_MS": "1500"})
     assert flags == abi.STAT_BEFORE_TREE | abi.STAT_RENDERED_TWICE      # ties: the frame was rendered again with the reference's order
     assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
+
+
+def test_material_coherent_variant_gives_the_same_film(pkg, load_scene):
+    """RTX_FUSED_REGROUP launches the variant of the lean flat path tracer whose lanes trade places by vertex class after every
+    closest-hit query (an experiment kept for its measurement): another lane computes a path, the path is the same (to the rounding
+    of a separately compiled kernel)."""
+    sd = load_scene("cornell_box")
+    kw = dict(width=200, height=113, samples_per_pixel=40, max_depth=40, seed=12)
+    with pkg.renderer.HipPathTracer(0) as pt:
+        pt.upload_scene(sd)
+        pt.set_camera(sd.camera(kw["width"], kw["height"]))
+        pt.set_settings(sd.settings(**kw))
+        want = pt.render().copy()
+        st0 = pt.last_stats
+        for minority in ("1", "16"):
+            os.environ["RTX_FUSED_REGROUP"] = minority
+            try:
+                got = pt.render().copy()
+                st = pt.last_stats
+            finally:
+                os.environ.pop("RTX_FUSED_REGROUP", None)
+            # another kernel, compiled on its own: the same arithmetic up to how the compiler contracts and orders it
+            bad = (np.abs(got - want) > 1e-3 * (1.0 + np.abs(want))).any(axis=2)
+            assert bad.mean() < 0.01, (minority, bad.mean())
+            assert abs(float(got.mean()) - float(want.mean())) < 1e-4 * float(want.mean())
+            assert st.samples == st0.samples and abs(int(st.segments) - int(st0.segments)) <= 0.003 * st0.segments and abs(int(st.rays_shadow) - int(st0.rays_shadow)) <= 0.003 * st0.rays_shadow
