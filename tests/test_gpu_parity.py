@@ -21,6 +21,7 @@ PATHPHOTON_F32_BAD_PIXELS_MAX = 0.015
 F32_ID_MISMATCH_RAYS = {"normal_mapped": 3, "kitchen_sink": 1, "soup": 1}   # of 4296 (soup: 10096) rays; every other scene: 0
 # Per-channel mean of the converged film against the reference's, relative: 1 %.
 CHANNEL_MEAN_TOL = 0.01
+PHOTON_CHANNEL_MEAN_TOL = 0.05   # PathPhoton: the mean of eight films with eight photon maps against the reference film with its ONE map (measured: 0.7 / 2.6 / 3.7 %; one map against one map: 0.7 / 3.4 / 4.7 %)
 
 
 def bits(a):
@@ -210,7 +211,7 @@ def test_f64_film_equals_oracle(name, nee, mis, pkg, oracle, tracer, load_scene)
 
 @pytest.mark.parametrize("name,pipe", [("cornell_box", "fused"), ("cornell_box_quad", "fused"), ("environment_demo", "fused"), ("textured", "fused"),
                                        ("cornell_box", "wavefront"), ("soup", "wavefront"), ("normal_mapped", "fused"), ("normal_mapped", "wavefront"),
-                                       ("sphere_field", "fused"), ("sphere_field", "wavefront")])
+                                       ("sphere_field", "fused"), ("sphere_field", "wavefront"), ("earth_demo", "fused")])
 def test_f32_pcg_film_equals_oracle_pcg(name, pipe, pkg, oracle, tracer, load_scene):
     """Single precision draws its samples from the pcg4d block generator (RTX_RNG_AUTO).  The oracle fed by the same
     generator renders the same paths in double precision: films agree to single-precision rounding, apart from the
@@ -227,12 +228,19 @@ def test_f32_pcg_film_equals_oracle_pcg(name, pipe, pkg, oracle, tracer, load_sc
     assert st.samples == W * H * spp
     assert abs(int(st.segments) - int(ost.segments)) <= 0.003 * ost.segments and abs(int(st.rays_shadow) - int(ost.rays_shadow)) <= 0.003 * ost.rays_shadow
     bad = (np.abs(got - ref) > 2e-3 * (1.0 + np.abs(ref))).any(axis=2)
-    assert bad.mean() < 0.02, (bad.mean(), np.abs(got - ref).max())
+    record_rate("f32_pcg_film_bad_pixels_" + name + "_" + pipe, rate=float(bad.mean()), mean_rel_diff=float(abs(got.mean() - ref.mean()) / (1 + ref.mean())))
+    # earth_demo (the image-textured instance of the fused kernel, TREE_UV): its checker floor lies in the plane y = 0, where the
+    # checker colour flips on the sign of a rounding residue (see test_f64_film_equals_oracle)
+    limit = 0.08 if name == "earth_demo" else 0.02
+    assert bad.mean() < limit, (bad.mean(), np.abs(got - ref).max())
     assert abs(got.mean() - ref.mean()) < 0.01 * (1 + ref.mean())
     # and the Philox stream is a different one
     pt.set_settings(sd.settings(precision=pkg.abi.PRECISION_F32, rng=pkg.abi.RNG_PHILOX, pipeline=pkg.abi.PIPELINE_FUSED, **over))
     other = pt.render().astype(np.float64)
-    assert (np.abs(other - got) > 1e-3).mean() > 0.2
+    if name != "earth_demo":   # (one point light, mirror-less geometry collapsed onto the origin: most of that film does not depend on the random numbers)
+        assert (np.abs(other - got) > 1e-3).mean() > 0.2
+    else:
+        assert not np.array_equal(other, got)
 
 
 @pytest.mark.parametrize("name", ["demo", "kitchen_points", "textured", "earth_demo", "kitchen_sink", "normal_mapped"])
@@ -469,14 +477,22 @@ def test_f32_film_within_tolerance_of_reference(name, pkg, tracer, load_scene):
     assert np.mean(errs) <= 1.25 * float(fx["noise_floor_relmse"]), (errs, float(fx["noise_floor_relmse"]))
     assert max(errs) <= 1.8 * float(fx["noise_floor_relmse"]), errs
     # many more samples than the reference: error must drop to the reference film's own noise
-    pt.set_settings(sd.settings(width=W, height=H, samples_per_pixel=16 * N, max_depth=int(fx["depth"]), seed=2025, mode=mode, **extra))
-    film16 = pt.render().astype(np.float64)
-    # (a PathPhoton film keeps the variance of its one photon map however many samples it takes)
-    assert rel_mse(film16, ref) <= (1.25 if extra else 0.6) * float(fx["noise_floor_relmse"])
+    if extra:
+        # A PathPhoton film keeps the variance of its one photon map however many samples it takes: the mean of films with
+        # different maps (the map follows the seed) does not.  What is left is the variance of the REFERENCE film's one map.
+        films = []
+        for seed in range(2025, 2025 + 8):
+            pt.set_settings(sd.settings(width=W, height=H, samples_per_pixel=2 * N, max_depth=int(fx["depth"]), seed=seed, mode=mode, **extra))
+            films.append(pt.render().astype(np.float64))
+        film16 = np.mean(films, axis=0)
+    else:
+        pt.set_settings(sd.settings(width=W, height=H, samples_per_pixel=16 * N, max_depth=int(fx["depth"]), seed=2025, mode=mode, **extra))
+        film16 = pt.render().astype(np.float64)
+    assert rel_mse(film16, ref) <= (0.85 if extra else 0.6) * float(fx["noise_floor_relmse"])   # (PathPhoton, measured: 0.75 of the floor)
     mg, mr = np.clip(film16, 0, 1).mean(axis=(0, 1)), np.clip(ref, 0, 1).mean(axis=(0, 1))
     record_rate("converged_" + name, relmse_mean=float(np.mean(errs)), relmse_max=float(max(errs)), noise_floor=float(fx["noise_floor_relmse"]),
                 relmse_16n=float(rel_mse(film16, ref)), channel_mean_rel_diff=[float(v) for v in (mg - mr) / mr])
-    assert np.all(np.abs(mg - mr) / mr < (0.2 if extra else CHANNEL_MEAN_TOL)), (mg, mr)
+    assert np.all(np.abs(mg - mr) / mr < (PHOTON_CHANNEL_MEAN_TOL if extra else CHANNEL_MEAN_TOL)), (mg, mr)
 
 
 @pytest.mark.parametrize("mode", ["pathtrace", "whitted", "bdpt", "pathphoton"])
