@@ -47,13 +47,15 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #ifndef RTX_FLAT_MIN_WAVES
 #define RTX_FLAT_MIN_WAVES 4
 #endif
-// The lean flat instances (see LEAN below) need fewer registers: measured best at 6 waves per SIMD
-// (3: 310.8 ms, 4: 309.7, 5: 298.9, 6: 292.3, 7: 296.1, 8: 330.4 on the 1080p Cornell box).
+// The lean flat instances (see LEAN below) need fewer registers.  With a grid of exactly the resident workgroups they were best at 6
+// waves per SIMD (3: 310.8 ms, 4: 309.7, 5: 298.9, 6: 292.3, 7: 296.1, 8: 330.4 on the 1080p Cornell box); with many short
+// workgroups (rtx_api.cpp) one more wave pays: 5: 167.9 ms, 6: 168.0, 7: 163.8, 8: 164.0 (800 x 800 x 128, two scenes: 15.2 / 14.6 /
+// 14.7 / 14.7).
 #ifndef RTX_LEAN_ENV_MIN_WAVES
 #define RTX_LEAN_ENV_MIN_WAVES 6   // lean instance that keeps the environment map
 #endif
 #ifndef RTX_LEAN_MIN_WAVES
-#define RTX_LEAN_MIN_WAVES 6
+#define RTX_LEAN_MIN_WAVES 7
 #endif
 #ifndef RTX_TREE_MIN_WAVES
 #define RTX_TREE_MIN_WAVES 3   // single-precision tree-walking instances: they sit at the 168-VGPR edge of 3 waves per SIMD
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4
 // ------------------------------------------------------------------------------------------
 constexpr int kRegroupWords = 25;
 template <int LEAN>
-__global__ __launch_bounds__(kBlock, RTX_LEAN_MIN_WAVES) void render_fused_regroup_kernel(DScene<float> sc, DCamera<float> cam, DRenderParams P, float* __restrict__ partial,
+__global__ __launch_bounds__(kBlock, 6) void render_fused_regroup_kernel(DScene<float> sc, DCamera<float> cam, DRenderParams P, float* __restrict__ partial,
                                                                                          DCounters* __restrict__ counters, int regroup_min_minority) {
   using R = float;
   if constexpr ((LEAN & 1) != 0) { sc.env.valid = 0; sc.env.importance = 0; }
