@@ -143,9 +143,11 @@ typedef struct rtx_settings {
 
 /* rtx_stats::flags.  RTX_STAT_BEFORE_TREE: the frame was rendered while the reference-order tree of a large scene was still being
  * built on the host (rtx_upload_scene returns before it is done, see there): exact ties in t between two bounded primitives went by
- * primitive number and were counted.  RTX_STAT_RENDERED_TWICE: there was such a tie, so the call waited for the tree and rendered
- * the frame again with the reference's tie order (the film is that second one; seconds_total covers both). */
-enum { RTX_STAT_BEFORE_TREE = 1, RTX_STAT_RENDERED_TWICE = 2 };
+ * primitive number, and the (pixel, sample chunk) work items they occurred in were noted.  RTX_STAT_TIES_REPAIRED: there were such
+ * ties, so the call waited for the tree and rendered those work items again with the reference's tie order (the other counters and
+ * times of the statistics are the first pass's; seconds_total covers everything).  RTX_STAT_RENDERED_TWICE: there were more of
+ * them than the list holds (65 536), and the whole frame was rendered again. */
+enum { RTX_STAT_BEFORE_TREE = 1, RTX_STAT_TIES_REPAIRED = 2, RTX_STAT_RENDERED_TWICE = 4 };
 typedef struct rtx_stats {
   uint64_t samples;          /* camera paths started */
   uint64_t rays_closest;     /* closest-hit queries executed */
@@ -217,9 +219,9 @@ int rtx_multi_set_gather(rtx_ctx* ctx, int mode);
  * the environment-map sampling tables (engine/texture.hpp:403-473).
  * Scenes of 2^18 or more bounded primitives: the call returns when the tables and the wide tree are on the device(s); the
  * reference-order tree is finished by a host thread of the library's own (it reads nothing of the caller's any more).  The
- * single-precision path tracer needs that tree only to decide exact ties in t the reference's way, so it renders at once: a frame
- * in which such a tie occurs is rendered again when the tree is there (rtx_stats::flags), every film is the one the finished tree
- * gives.  Whatever walks the reference-order tree itself - rtx_trace_closest*, double precision, the other render modes,
+ * single-precision path tracer needs that tree only to decide exact ties in t the reference's way, so it renders at once: the work
+ * items of a frame in which such ties occur are rendered again when the tree is there (rtx_stats::flags), every film is the one the
+ * finished tree gives.  Whatever walks the reference-order tree itself - rtx_trace_closest*, double precision, the other render modes,
  * rtx_get_bvh_info, rtx_get_reference_bvh - waits for it.  A scene in which a primitive's box is flat along an axis is built the
  * ordinary way (the reference cannot reach some such primitives, which the wide tree has to know), as is every scene when the
  * environment variable RTX_EAGER_TREE is set. */

@@ -75,7 +75,7 @@ int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, cons
     // with the settings that do not vary pinned (less code, fewer live scalars: the kernel keeps the scene in scalar registers
     // and spills what does not fit to vector lanes).  Measured, 800x800x128: the Cornell box with a quad light 9.88 -> 9.47 ms with
     // instance 27 instead of 3; the same pinning for the environment-map scene (30 instead of 6) was 4 % slower and is not used.
-    if (L.regroup > 0 && !sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && sc.n_quads == 0 && P.use_nee && P.use_mis && P.rng == 1 /* RNG_PCG4D */)
+    if (L.regroup > 0 && !P.item_list && !sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && sc.n_quads == 0 && P.use_nee && P.use_mis && P.rng == 1 /* RNG_PCG4D */)
       hipLaunchKernelGGL((render_fused_regroup_kernel<31>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.regroup);   // experiment: material-coherent waves
     else if (!sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && sc.n_quads == 0 && P.use_nee && P.use_mis && P.rng == 1 /* RNG_PCG4D */)
       hipLaunchKernelGGL((render_fused_kernel<float, MODE_FLAT, true, INTEG_PATH, 31>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);

@@ -83,12 +83,14 @@ template <class R> struct Cand {
   // succeeded before it.  uv_kind: 0 none (0,0), 1 values in (ua, ub), 2 sphere `uv_idx` at t = ua.
   R ua, ub;
   int uv_kind, uv_idx;
+  int tied;   // the walk decided an exact tie in t without the reference's leaf order (tie_goes_to)
 };
 
 template <class R> struct Hit {
   V3<R> p, n;
   R t, u, v;
   int front, mat, type, idx;
+  int tied;   // Cand::tied of the query that found it
 };
 
 // ------------------------------------------------------------------------------------------
@@ -217,7 +219,7 @@ template <class R> RTX_DEV bool disk_t(const DDisk<R>& dl, const Ray<R>& r, R t_
 }
 
 template <class R> RTX_DEV void cand_init(Cand<R>& c, R t_max) {
-  c.t = t_max; c.type = -1; c.idx = -1; c.ua = R(0); c.ub = R(0); c.uv_kind = 0; c.uv_idx = -1;
+  c.t = t_max; c.type = -1; c.idx = -1; c.ua = R(0); c.ub = R(0); c.uv_kind = 0; c.uv_idx = -1; c.tied = 0;
 }
 
 // One bounded primitive (sphere / triangle / box) against the current candidate.
@@ -260,7 +262,7 @@ template <class R> RTX_DEV void sphere_uv(V3<R> on, R& u, R& v) {
 // make on success: sphere.hpp:94-98, primitives.hpp:50-53,112-116,180-195,302-305,419-422,
 // scene.hpp:657,669).  WANT_UV also resolves hit_record::u/v.
 template <class R, bool WANT_UV> RTX_DEV void finalize_hit(const DScene<R>& sc, const Ray<R>& r, const Cand<R>& c, Hit<R>& h) {
-  h.t = c.t; h.type = c.type; h.idx = c.idx;
+  h.t = c.t; h.type = c.type; h.idx = c.idx; h.tied = 0;
   h.p = at(r, c.t);
   h.u = R(0); h.v = R(0);
   switch (c.type) {
@@ -404,13 +406,13 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
 // its primitives.  On an exact tie in t the primitive later in the reference's leaf order wins, whatever the visiting order
 // (DScene::rank; best_p = the current winner's primitive number).
 // ------------------------------------------------------------------------------------------
-struct Walk8 { V3<float> inv; int node, sp, best_p; };
+struct Walk8 { V3<float> inv; int node, sp, best_p, tied; };
 
 RTX_DEV void walk8_begin(Walk8& w, const Ray<float>& r) {
   // the quantised boxes multiply 1/d by box units: keep it finite (a direction component below 1e-18 moves the ray by less
   // than 1e-9 over the longest ray, so the slab of that axis is constant along it either way)
   w.inv = {fminf(fmaxf(1.0f / r.d.x, -1e18f), 1e18f), fminf(fmaxf(1.0f / r.d.y, -1e18f), 1e18f), fminf(fmaxf(1.0f / r.d.z, -1e18f), 1e18f)};
-  w.node = 0; w.sp = 0; w.best_p = -1;
+  w.node = 0; w.sp = 0; w.best_p = -1; w.tied = 0;
 }
 RTX_DEV bool walk8_at_inner(const Walk8& w) { return w.node >= 0 && w.node != kWalkDone; }
 RTX_DEV bool walk8_at_leaf(const Walk8& w) { return w.node < 0; }
@@ -532,11 +534,17 @@ RTX_DEV bool leaf_tri_t(const float* v, const Ray<float>& r, float t_min, float 
 // Exact tie in t between primitive `p` and the current winner `best` (primitive numbers): does p win?  The later one in the
 // reference's leaf order does (Scene::hit accepts t == closest_so_far, ref: engine/scene.hpp:602-631).  While that order is
 // not on the device yet (the host is still building the reference-order tree) the higher primitive number wins and the tie is
-// counted, so that the host can render the frame again once the order is known (such ties are rare: it hardly ever has to).
-RTX_DEV bool tie_goes_to(const DScene<float>& sc, int p, int best) {
+// noted in the walk's state: the caller lists the work item the ray belongs to, and the host renders those items again once the
+// order is known (about one closest-hit query in ten million ties on a soup of small triangles).
+RTX_DEV bool tie_goes_to(const DScene<float>& sc, int p, int best, Walk8& w) {
   if (sc.rank) return sc.rank[p] > sc.rank[best];
-  if (sc.ties) atomicAdd(sc.ties, 1ull);
+  w.tied = 1;
   return p > best;
+}
+// Notes work item `item` as one in which such a tie occurred.
+RTX_DEV void note_tied_item(const DRenderParams& P, DCounters* counters, uint32_t item) {
+  const unsigned long long k = atomicAdd(&counters->ties, 1ull);
+  if (P.tie_list && k < (unsigned long long)P.tie_cap) P.tie_list[k] = item;
 }
 
 // Tests the primitive of the leaf record with code `leaf` (a ~unit) against the ray; updates the candidate and the tie state.
@@ -550,7 +558,7 @@ RTX_DEV void walk8_leaf_test(const DScene<float>& sc, const Ray<float>& r, float
   float t, u, vv;
   // (the range check on ref costs two instructions and keeps a record that is no leaf record from ever being taken for a triangle)
   bool ok = leaf_tri_t(v, r, t_min, c.t, t, u, vv) && (uint32_t)(ref - sc.n_spheres) < (uint32_t)sc.n_tris;
-  if (ok && t == c.t && w.best_p >= 0) ok = tie_goes_to(sc, ref, w.best_p);   // exact tie: the later one in the reference's order wins
+  if (ok && t == c.t && w.best_p >= 0) ok = tie_goes_to(sc, ref, w.best_p, w);   // exact tie: the later one in the reference's order wins
   if (ok) { c.t = t; c.type = PRIM_TRIANGLE; c.idx = ref - sc.n_spheres; c.uv_kind = 1; c.ua = u; c.ub = vv; w.best_p = ref; }
   const int p = -2 - ref;
   const bool sphere = (uint32_t)p < (uint32_t)sc.n_spheres, box = (uint32_t)(p - sc.n_spheres - sc.n_tris) < (uint32_t)sc.n_boxes;
@@ -560,7 +568,7 @@ RTX_DEV void walk8_leaf_test(const DScene<float>& sc, const Ray<float>& r, float
     Cand<float> trial = c;
     test_bounded(sc, type, idx, r, t_min, trial);
     const bool changed = trial.type == type && trial.idx == idx && (trial.t != c.t || c.type != type || c.idx != idx);
-    if (changed && !(trial.t == c.t && w.best_p >= 0 && !tie_goes_to(sc, p, w.best_p))) { c = trial; w.best_p = p; }
+    if (changed && !(trial.t == c.t && w.best_p >= 0 && !tie_goes_to(sc, p, w.best_p, w))) { c = trial; w.best_p = p; }
   }
 }
 
@@ -586,6 +594,7 @@ template <bool ANY> RTX_DEV bool walk8(const DScene<float>& sc, const Ray<float>
 #ifdef RTX_WALK_STATS
   c.ua = (float)walk_steps; c.uv_kind = 1;
 #endif
+  c.tied = w.tied;
   return c.type >= 0;
 }
 
@@ -603,6 +612,7 @@ template <class R, bool WANT_UV> RTX_DEV bool closest_hit(const DScene<R>& sc, c
   test_unbounded(sc, r, t_min, c);
   if (c.type < 0) return false;
   finalize_hit<R, WANT_UV>(sc, r, c, h);
+  h.tied = c.tied;
   return true;
 }
 
@@ -1078,7 +1088,7 @@ RTX_DEV void flat_closest_tk(const DScene<float>& sc, const Ray<float>& r, float
 RTX_DEV bool flat_hit_from(const DScene<float>& sc, const Ray<float>& r, float best, int k, Hit<float>& h) {
   if (k < 0) return false;
   const DFlatRec rec = sc.flat[k];
-  h.t = best; h.type = rec.type; h.idx = rec.idx; h.mat = rec.mat; h.u = 0.f; h.v = 0.f;
+  h.t = best; h.type = rec.type; h.idx = rec.idx; h.mat = rec.mat; h.u = 0.f; h.v = 0.f; h.tied = 0;
   h.p = at(r, best);
   V3<float> abc = {rec.a, rec.b, rec.c};
   V3<float> on = rec.w != 0.f ? (h.p - abc) * rec.w : abc;
@@ -1153,7 +1163,7 @@ template <class R> RTX_DEV void path_begin(PathState<R>& ps, const DCamera<R>& c
 namespace rtx {
 
 // What one vertex did, for the statistics: bit 0 = a shadow ray was cast, bit 1 = the vertex was shaded.
-enum : uint32_t { STEP_SHADOW = 1u, STEP_SHADED = 2u };
+enum : uint32_t { STEP_SHADOW = 1u, STEP_SHADED = 2u, STEP_TIED = 4u };   // TIED: the vertex's closest-hit query decided a tie without the reference's order
 
 // Shade the vertex a trace of ps.ray found (`hit`, `rec`): settle the previous vertex's pending
 // MIS term, add emission, sample a light, scatter, Russian roulette.  The visibility query of
@@ -1404,7 +1414,8 @@ RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMateria
   } else if constexpr (INTEG == INTEG_WHITTED) {
     return whitted_vertex(ps, hit, rec, sc, mats, P, key, [&](const Ray<R>& sr, R t_max) { return trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st); }, extra_shadow);
   } else {
-    return path_vertex_impl<R, INTEG == INTEG_PATH_MNEE, NMAP>(
+    const uint32_t tied = (hit && rec.tied) ? STEP_TIED : 0u;
+    return tied | path_vertex_impl<R, INTEG == INTEG_PATH_MNEE, NMAP>(
         ps, hit, rec, sc, mats, P, key,
         [&](const Ray<R>& sr, R t_max, V3<R> contrib) {
           const bool visible = !trace_occluded<R, MODE, true>(sc, sr, R(0.001), t_max, st);   // light-sample rays are normalised

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4
   const DMaterial<R>* mats = sc.mats;
   if constexpr (LDS_MATS) mats = stage_materials(sc);
   const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
-  const uint32_t n_items = npix * (uint32_t)P.n_chunks;
+  const uint32_t n_items = P.item_list ? P.n_list : npix * (uint32_t)P.n_chunks;   // (a repair pass renders the listed items only)
   const uint32_t stride = gridDim.x * blockDim.x;
   uint32_t next = blockIdx.x * blockDim.x + threadIdx.x;
   LaneStack st = lane_stack(stack_first_int);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4
 
   auto fetch = [&]() -> bool {
     if (next >= n_items) return false;
-    cur = next;
+    cur = P.item_list ? P.item_list[next] : next;
     next += stride;
     uint32_t chunk = cur / npix;
     uint32_t pix = cur - chunk * npix;
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4
     while (active) {
       w_steps += (uint32_t)__popcll(__ballot(1));
       const uint32_t did = path_step<R, MODE, INTEG, MODE == MODE_TREE_UV && (LEAN & 32) == 0>(ps, sc, mats, P, key, st, extra_traces, extra_shadow);
+      if constexpr (MODE != MODE_FLAT && sizeof(R) == 4) { if (did & STEP_TIED) note_tied_item(P, counters, cur); }
       w_shadow += (uint32_t)__popcll(__ballot((did & STEP_SHADOW) != 0));
       w_shaded += (uint32_t)__popcll(__ballot((did & STEP_SHADED) != 0));
       bool started = false;

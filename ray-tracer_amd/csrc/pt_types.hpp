@@ -93,8 +93,8 @@ template <class R> struct DScene {
   const DNodeRef* nodes; const DPrimRef* prims;     // double precision: the reference-order tree, walked nearest child first (left child of node i = i + 1); the reference's primitive order
   const DNode8* nodes8;                                // single-precision traversal layout: 64-byte units, node records and leaf records (NULL in the double scene and for scenes tested linearly)
   const int32_t* rank;                                 // position of every bounded primitive (numbered as in DLeaf::ref) in the reference's leaf order; NULL while the
-                                                       // reference-order tree is still being built on the host: exact ties in t then go by primitive number and are counted
-  unsigned long long* ties;                            // where such ties are counted (DCounters::ties of the render; set per launch)
+                                                       // reference-order tree is still being built on the host: exact ties in t then go by primitive number, and the
+                                                       // (pixel, chunk) work item they occur in is noted for a second look (DRenderParams::tie_list)
   const DFlatRec* flat;                                // flat scenes only (single precision)
   float bb_lo[3], bb_scale[3];                         // the eight-wide tree's root box as a 128^3 grid: cell = (p - bb_lo) * bb_scale (ray sorting)
   float wt_anchor[3], wt_step[3];                      // the grid the node origins of the eight-wide tree lie on (DNode8::org)
@@ -128,6 +128,13 @@ struct DRenderParams {
   // of ph_cand_cap entries (distances, then photon numbers) per wave of the grid; 0 / NULL otherwise
   void* ph_cand;
   double gather_radius;
+  // Work items to render instead of all of them (NULL: all): the repair pass of a frame that was rendered before the
+  // reference-order tree arrived re-renders the items in which an exact tie in t occurred.  item index i -> item_list[i].
+  const uint32_t* item_list;
+  uint32_t n_list;
+  // Where a render without DScene::rank notes such items: tie_list[k] for the k-th tie, k = DCounters::ties++, while k < tie_cap.
+  uint32_t* tie_list;
+  uint32_t tie_cap;
 };
 
 // PathPhoton (pt_photon.hpp)
@@ -141,7 +148,8 @@ template <class R> struct DPhotonNode { R p[3]; int32_t axis; };       // kd-tre
 template <class R> struct DPhotonData { R dir[3]; R power[3]; };
 template <class R> struct DPhotonBox { R lo[3]; R hi[3]; };
 
-// ties: exact ties in t between two bounded primitives that were decided WITHOUT the reference's leaf order (DScene::rank == NULL)
+// ties: closest-hit queries with an exact tie in t between two bounded primitives that was decided WITHOUT the reference's leaf
+// order (DScene::rank == NULL); the work items they belong to are in DRenderParams::tie_list
 struct DCounters { unsigned long long samples, closest, shadow, segments, nodes_visited, prims_tested, ties; };
 
 // One closest-hit answer in the layout of rtx_hit (include/rtx_hip.h).

@@ -188,6 +188,7 @@ struct rtx_ctx {
   DCamera<float> cam_f;
   DCamera<double> cam_d;
   DeviceBuffer partial, film, counters, rays, hits, post_in, post_out, bdpt_store;
+  DeviceBuffer tie_list, repair_counters;   // work items with a tie decided before the reference-order tree arrived; the counters of their repair pass
   DeviceBuffer ph_lights, ph_targets, ph_out, ph_nodes, ph_data, ph_boxes, ph_cand;   // PathPhoton: photon pass plan, its raw output, the kd-tree
   WavefrontPool wf;         // wavefront-pipeline queues, allocated on first use
   // The photon map in ph_nodes / ph_data / ph_boxes and what it was built from: a render with the same inputs reuses it
@@ -481,6 +482,7 @@ int rtx_destroy(rtx_ctx* c) {
   c->gather.release();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->scene.release();
+  c->tie_list.release(); c->repair_counters.release();
   c->partial.release(); c->film.release(); c->counters.release(); c->rays.release(); c->hits.release(); c->post_in.release(); c->post_out.release(); c->bdpt_store.release();
   c->ph_lights.release(); c->ph_targets.release(); c->ph_out.release(); c->ph_nodes.release(); c->ph_data.release(); c->ph_boxes.release(); c->ph_cand.release();
   c->wf.release();
@@ -634,8 +636,9 @@ int rtx_get_reference_bvh(rtx_ctx* c, rtx_bvh_node* nodes, size_t n_nodes, int32
   });
 }
 
+constexpr uint32_t kTieListCap = 1u << 16;   // tied work items a frame can note for its repair pass; beyond, the whole frame is rendered again
 static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, bool no_alloc = false, bool bare = false,
-                          bool stream_as_given = false);
+                          bool stream_as_given = false, uint32_t repair_n = 0);
 
 // Second half of a render: waits for the kernels render_enqueue put on the stream and turns the counters and event times into
 // statistics.
@@ -649,15 +652,30 @@ static int render_collect(rtx_ctx* c, rtx_stats* stats) {
   rtx_stats st = pd.st;
   const DCounters hc = *c->h_counters;
   if (pd.optimistic && hc.ties > 0) {
-    // a tie in t was decided without the reference's leaf order: wait for that order and render the call again
+    // Ties in t were decided without the reference's leaf order: wait for that order, then render the work items they occurred in
+    // again (a few dozen of the 33 M of a 1080p frame at 64 spp); if there were more than the list holds, the whole frame.
     const rtx_ctx::Pending again = pd;
     const int trc = need_tree(c);
     if (trc != RTX_OK) return trc;
-    const int rc = render_enqueue(c, &again.settings, again.host_out, again.dev_out, again.user_stream, again.no_alloc, false, again.stream_as_given);
-    if (rc != RTX_OK) return rc;
-    c->pending.wall0 = again.wall0;
-    c->pending.st.flags |= RTX_STAT_BEFORE_TREE | RTX_STAT_RENDERED_TWICE;
-    return render_collect(c, stats);
+    if (hc.ties <= (unsigned long long)kTieListCap) {
+      // every item once: the queue pipeline adds the light samples of an item's last path to its chunk sum, which two concurrent
+      // renders of one item would do twice
+      std::vector<uint32_t> items((size_t)hc.ties);
+      HIP_TRY(hipMemcpy(items.data(), c->tie_list.ptr, items.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      std::sort(items.begin(), items.end());
+      items.erase(std::unique(items.begin(), items.end()), items.end());
+      HIP_TRY(hipMemcpy(c->tie_list.ptr, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      const int rc = render_enqueue(c, &again.settings, again.host_out, again.dev_out, again.user_stream, again.no_alloc, false, again.stream_as_given, (uint32_t)items.size());
+      if (rc != RTX_OK) return rc;
+      HIP_TRY(hipStreamSynchronize(pd.stream));
+      st.flags |= RTX_STAT_TIES_REPAIRED;
+    } else {
+      const int rc = render_enqueue(c, &again.settings, again.host_out, again.dev_out, again.user_stream, again.no_alloc, false, again.stream_as_given);
+      if (rc != RTX_OK) return rc;
+      c->pending.wall0 = again.wall0;
+      c->pending.st.flags |= RTX_STAT_BEFORE_TREE | RTX_STAT_RENDERED_TWICE;
+      return render_collect(c, stats);
+    }
   }
   if (pd.optimistic) st.flags |= RTX_STAT_BEFORE_TREE;
   float ms = 0.f;
@@ -684,10 +702,15 @@ static void settle(rtx_ctx* c) {
 // counters to pinned host memory) on the stream; render_collect finishes it.  `no_alloc`: the render may not allocate
 // (rtx_render_device_noalloc): its chunk sums and counters go to the device's scratch array, and whatever would need another
 // buffer is refused; with `bare` as well it records nothing but kernels (no event, no copy) and leaves nothing to collect.
+// repair_n > 0: the repair pass of the frame just rendered - the first repair_n work items of c->tie_list are rendered again (with the
+// tie order that has arrived meanwhile) into the chunk sums the first pass left, and the film is reduced again; nothing is timed,
+// armed or counted for the caller (its counters go to c->repair_counters).
 static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, void* dev_out, hipStream_t user_stream, bool no_alloc, bool bare,
-                          bool stream_as_given /* NULL is HIP's default stream, not the context's own */) {
+                          bool stream_as_given /* NULL is HIP's default stream, not the context's own */, uint32_t repair_n) {
   if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "NULL argument");
-  settle(c);
+  const bool repair = repair_n > 0;
+  if (repair) bare = true;   // no events, no arming
+  else settle(c);
   if (!c->has_scene) return fail(RTX_ERR_NOT_READY, "render before upload_scene");
   if (!c->has_camera) return fail(RTX_ERR_NOT_READY, "render before set_camera");
   if (s->width <= 0 || s->height <= 0 || s->samples_per_pixel <= 0 || s->max_depth < 0)
@@ -772,6 +795,11 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     }
     if (trc != RTX_OK) { c->has_scene = false; return fail(trc, "reference-order tree: %s", terr.c_str()); }
   }
+  if (optimistic) {
+    if (!c->tie_list.ensure((size_t)kTieListCap * sizeof(uint32_t))) return fail(RTX_ERR_OUT_OF_MEMORY, "tie list");
+    P.tie_list = (uint32_t*)c->tie_list.ptr; P.tie_cap = kTieListCap;
+  }
+  if (repair) { P.item_list = (const uint32_t*)c->tie_list.ptr; P.n_list = repair_n; }
 
   float* d_film = (float*)dev_out;
   void* partial_ptr = nullptr;
@@ -782,14 +810,16 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     static_assert(sizeof(DCounters) <= kScratchHeader, "counters must fit the scratch header");
     counters_ptr = (DCounters*)c->scratch_dev;
     partial_ptr = c->scratch_dev + kScratchHeader;
+    if (repair) return fail(RTX_ERR_HIP, "internal: repair pass of a no-allocation render");   // (such renders wait for the tree)
     launch_zero_words((uint32_t*)counters_ptr, (unsigned)(sizeof(DCounters) / 4), stream);   // a fill kernel, not a memset node: callers may capture this call
   } else {
     if (!d_film) {
       if (!c->film.ensure(npix * 3 * sizeof(float))) return fail(RTX_ERR_OUT_OF_MEMORY, "film buffer");
       d_film = (float*)c->film.ptr;
     }
-    if (!c->counters.ensure(sizeof(DCounters))) return fail(RTX_ERR_OUT_OF_MEMORY, "counters");
-    counters_ptr = (DCounters*)c->counters.ptr;
+    DeviceBuffer& cb = repair ? c->repair_counters : c->counters;
+    if (!cb.ensure(sizeof(DCounters))) return fail(RTX_ERR_OUT_OF_MEMORY, "counters");
+    counters_ptr = (DCounters*)cb.ptr;
     HIP_TRY(hipMemsetAsync(counters_ptr, 0, sizeof(DCounters), stream));
   }
 
@@ -798,15 +828,16 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
   if (!photon && !bare) HIP_TRY(hipEventRecord(c->ev0, stream));   // PathPhoton records it behind its photon pass
   if (pipeline == RTX_PIPELINE_FUSED) {
     const size_t elem = f64 ? sizeof(double) : sizeof(float);
-    const unsigned long long items = npix * (unsigned long long)P.n_chunks;
-    if (items >= 0x7fffffffull) return fail(RTX_ERR_INVALID_ARGUMENT, "film too large for one launch (%llu work items)", items);
+    const unsigned long long all_items = npix * (unsigned long long)P.n_chunks;
+    if (all_items >= 0x7fffffffull) return fail(RTX_ERR_INVALID_ARGUMENT, "film too large for one launch (%llu work items)", all_items);
+    const unsigned long long items = repair ? (unsigned long long)repair_n : all_items;   // work items this launch renders
     if (no_alloc) {
-      if ((unsigned long long)items * 3ull * elem > kScratchBytes - kScratchHeader)
+      if ((unsigned long long)all_items * 3ull * elem > kScratchBytes - kScratchHeader)
         return fail(RTX_ERR_INVALID_ARGUMENT, "the no-allocation render holds %llu bytes of chunk sums: %d x %d pixels in %d sample chunks need %llu (at most %llu pixel-chunks)",
-                    (unsigned long long)(kScratchBytes - kScratchHeader), P.width, P.rows, P.n_chunks, (unsigned long long)items * 3ull * elem,
+                    (unsigned long long)(kScratchBytes - kScratchHeader), P.width, P.rows, P.n_chunks, (unsigned long long)all_items * 3ull * elem,
                     (unsigned long long)((kScratchBytes - kScratchHeader) / (3 * elem)));
     } else {
-      if (!c->partial.ensure((size_t)items * 3 * elem)) return fail(RTX_ERR_OUT_OF_MEMORY, "chunk-sum buffer (%llu bytes)", (unsigned long long)(items * 3 * elem));
+      if (!c->partial.ensure((size_t)all_items * 3 * elem)) return fail(RTX_ERR_OUT_OF_MEMORY, "chunk-sum buffer (%llu bytes)", (unsigned long long)(all_items * 3 * elem));
       partial_ptr = c->partial.ptr;
     }
     FusedLaunch L;
@@ -857,8 +888,7 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     if (per_lane) grid = std::max(grid, (items + kBlock * per_lane - 1) / (kBlock * per_lane));
     L.grid = (int)grid;
     int lrc;
-    DScene<float> scf = c->scene.dev_f;
-    scf.ties = &counters_ptr->ties;
+    const DScene<float>& scf = c->scene.dev_f;
     if (photon) {   // the photon pass comes first (ref: engine/renderer.cpp:344-372); its rays are counted as closest-hit queries
       // the photon kernel is the tree-walking instance whatever the render kernel is (a flat scene of 13 to 16 spheres walks
       // its tree there), so its traversal stacks are sized from the scene alone
@@ -909,13 +939,15 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     std::string err;
     if (stack_words(c, false) * kBlock * sizeof(int) > c->lds_per_block)
       return fail(RTX_ERR_UNSUPPORTED, "this scene's traversal stacks need %zu bytes of LDS per workgroup, the device gives %zu", stack_words(c, false) * kBlock * sizeof(int), c->lds_per_block);
-    DScene<float> scw = c->scene.dev_f;
-    scw.ties = &counters_ptr->ties;
-    int rc = wavefront_render(c->wf, scw, c->cam_f, P, d_film, counters_ptr, c->n_cus, c->scene.fused_mode(false), (int)stack_words(c, false), stream, st.kernel_launches, err);
+    int rc = wavefront_render(c->wf, c->scene.dev_f, c->cam_f, P, d_film, counters_ptr, c->n_cus, c->scene.fused_mode(false), (int)stack_words(c, false), stream, st.kernel_launches, err);
     if (rc != RTX_OK) return fail(rc, "wavefront: %s", err.c_str());
     HIP_TRY(hipEventRecord(c->evm, stream));
   }
   HIP_TRY(hipGetLastError());
+  if (repair) {   // the caller (render_collect) waits for the stream
+    if (host_out) HIP_TRY(hipMemcpyAsync(host_out, d_film, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    return RTX_OK;
+  }
   if (bare) return RTX_OK;   // kernels only: the caller synchronises (or replays) its stream
   HIP_TRY(hipEventRecord(c->ev1, stream));
   HIP_TRY(hipMemcpyAsync(c->h_counters, counters_ptr, sizeof(DCounters), hipMemcpyDeviceToHost, stream));

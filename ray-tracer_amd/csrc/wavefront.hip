@@ -170,8 +170,11 @@ __global__ __launch_bounds__(64) void wf_stats_fold(const WfStatBank* __restrict
 }
 
 // (pixel, chunk) work item `item` of a render: where its pixel lies and which samples it covers.
-struct WorkItem { uint32_t xy, pixel, s_begin, s_end; };
-RTX_DEV WorkItem work_item(const DRenderParams& P, uint32_t item) {
+struct WorkItem { uint32_t xy, pixel, s_begin, s_end, id; };   // id: the item's number in the frame (where its chunk sum goes)
+RTX_DEV uint32_t work_items(const DRenderParams& P) { return P.item_list ? P.n_list : (uint32_t)P.rows * (uint32_t)P.width * (uint32_t)P.n_chunks; }
+// The index-th work item of the launch: item `index` of the frame, or, in a repair pass, the index-th item of its list.
+RTX_DEV WorkItem work_item(const DRenderParams& P, uint32_t index) {
+  const uint32_t item = P.item_list ? P.item_list[index] : index;
   const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
   const uint32_t chunk = item / npix;
   const uint32_t pix = item - chunk * npix;
@@ -179,7 +182,7 @@ RTX_DEV WorkItem work_item(const DRenderParams& P, uint32_t item) {
   const uint32_t x = pix - row_local * (uint32_t)P.width;
   const uint32_t y = (uint32_t)P.shard_index + row_local * (uint32_t)P.shard_count;
   const uint32_t s = chunk * (uint32_t)P.chunk_spp;
-  return {(y << 16) | x, y * (uint32_t)P.width + x, s, s + (uint32_t)P.chunk_spp < (uint32_t)P.spp ? s + (uint32_t)P.chunk_spp : (uint32_t)P.spp};
+  return {(y << 16) | x, y * (uint32_t)P.width + x, s, s + (uint32_t)P.chunk_spp < (uint32_t)P.spp ? s + (uint32_t)P.chunk_spp : (uint32_t)P.spp, item};
 }
 
 // Slot i takes work item i (a render has at least as many items as slots) and starts its first sample; all slots go into ray
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(kStreamBlock) void wf_start(DCamera<float> cam, DRe
   const bool live = sl < A.n_slots;
   if (live) {
     const WorkItem it = work_item(P, sl);
-    A.cur[sl] = sl; A.next[sl] = sl + A.n_slots; A.xy[sl] = it.xy; A.pixel[sl] = it.pixel; A.s_end[sl] = it.s_end;
+    A.cur[sl] = it.id; A.next[sl] = sl + A.n_slots; A.xy[sl] = it.xy; A.pixel[sl] = it.pixel; A.s_end[sl] = it.s_end;
     PathState<float> ps;
     PathKey key = {it.pixel, P.seed, it.s_begin, (uint32_t)P.rng};
     path_begin(ps, cam, P, (int)(it.xy & 0xffffu), (int)(it.xy >> 16), key);
@@ -316,7 +319,7 @@ RTX_DEV uint32_t feed_take(WaveFeed& f, uint32_t* cursor, bool want, uint32_t n)
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<float> sc, WfArrays A, WfControl* ctl, int nq /* the queue's counter */, int stack_levels, DCounters* counters,
-                                                    const uint32_t* __restrict__ order /* the queue's entries in the order to take them */) {
+                                                    const uint32_t* __restrict__ order /* the queue's entries in the order to take them */, DRenderParams P) {
   const uint32_t n = ctl->n_q_[nq].v;
   uint32_t n_nodes = 0, n_prims = 0;   // node records and leaf records this lane fetched
   WaveFeed feed = {0u, 0u, false};
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
   Cand<float> c;
   Walk8 w;
   cand_init(c, 1e9f);
-  w.node = kWalkDone; w.sp = 0; w.best_p = -1; w.inv = {0.f, 0.f, 0.f};
+  w.node = kWalkDone; w.sp = 0; w.best_p = -1; w.tied = 0; w.inv = {0.f, 0.f, 0.f};
   int state = 0;   // 0 no ray, 1 walking, 2 walk finished, result not yet stored
   // the next ray, loaded while the current one is walked, so that a lane changes rays without waiting on memory
   uint32_t nslot = 0;
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_extend(DScene<f
         }
         A.hit_t[slot] = t; A.hit_id[slot] = id;
         if constexpr (MODE == MODE_TREE_UV) { A.hit_ua[slot] = ua; A.hit_ub[slot] = ub; A.hit_uv[slot] = uv; }
+        if (tree && w.tied) { note_tied_item(P, counters, A.cur[slot]); w.tied = 0; }   // (decided without the reference's order)
         state = 0;
       }
       if (state == 0 && have_next) {   // take over the prefetched ray
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
     // The path ended: it joins the chunk sum, and the slot starts its next sample or takes its next (pixel, chunk) work item.
     const uint32_t s_end = A.s_end[slot];
     V3<float> sum = {A.sum[0][slot] + ps.acc.x, A.sum[1][slot] + ps.acc.y, A.sum[2][slot] + ps.acc.z};
-    WorkItem it = {A.xy[slot], pixel, s, s_end};
+    WorkItem it = {A.xy[slot], pixel, s, s_end, 0u};
     if (s == s_end) {
       const uint32_t done = A.cur[slot];
       float* o = partial + (size_t)done * 3u;
@@ -479,11 +483,11 @@ __global__ __launch_bounds__(kStreamBlock) void wf_shade(DScene<float> sc, DCame
       sh_target = kShadowToItem | done;
       sum = {0.f, 0.f, 0.f};
       const uint32_t item = A.next[slot];
-      if (item >= (uint32_t)P.rows * (uint32_t)P.width * (uint32_t)P.n_chunks) {
+      if (item >= work_items(P)) {
         live = false;
       } else {
         it = work_item(P, item);
-        A.cur[slot] = item; A.next[slot] = item + A.n_slots; A.xy[slot] = it.xy; A.pixel[slot] = it.pixel; A.s_end[slot] = it.s_end;
+        A.cur[slot] = it.id; A.next[slot] = item + A.n_slots; A.xy[slot] = it.xy; A.pixel[slot] = it.pixel; A.s_end[slot] = it.s_end;
       }
     }
     if (live) {
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(kBlock, RTX_WALK_MIN_WAVES) void wf_connect(DScene<
   Cand<float> c;
   Walk8 w;
   cand_init(c, 1e9f);
-  w.node = kWalkDone; w.sp = 0; w.best_p = -1; w.inv = {0.f, 0.f, 0.f};
+  w.node = kWalkDone; w.sp = 0; w.best_p = -1; w.tied = 0; w.inv = {0.f, 0.f, 0.f};
   int state = 0;   // 0 no ray, 1 walking, 2 finished (occluded), 3 finished (visible)
   uint32_t ni = 0;   // the next shadow ray, loaded while the current one is walked
   float nt_max = 0.f;
@@ -619,7 +623,7 @@ template <int MODE> void launch_turn_kernels(const DScene<float>& sc, const DCam
   }
   if (sorted) sort_queue(q_out, n_out, 0);
   if (!pool.mark(stream)) pool.timing_ok = false;   // an event could not be made or recorded: this render reports no traversal time
-  hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, n_out, stack_levels, counters, sorted ? A.order_out : A.q[q_out]);
+  hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, n_out, stack_levels, counters, sorted ? A.order_out : A.q[q_out], P);
   if (!pool.mark(stream)) pool.timing_ok = false;
   ++launches;
 }
@@ -639,15 +643,17 @@ template <int MODE> int walk_blocks_per_cu(int stack_levels) {
 int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* d_film,
                      DCounters* counters, int n_cus, int mode, int stack_levels, hipStream_t stream, uint32_t& launches, std::string& err) {
   const unsigned long long npix = (unsigned long long)P.rows * P.width;
-  const unsigned long long items = npix * (unsigned long long)P.n_chunks;
-  if (items >= 0x7fffffffull) { err = "film too large for one launch"; return RTX_ERR_INVALID_ARGUMENT; }
+  const unsigned long long all_items = npix * (unsigned long long)P.n_chunks;
+  if (all_items >= 0x7fffffffull) { err = "film too large for one launch"; return RTX_ERR_INVALID_ARGUMENT; }
+  // (a repair pass renders the listed work items only; the chunk sums of the others stay as the first pass left them)
+  const unsigned long long items = P.item_list ? (unsigned long long)P.n_list : all_items;
   for (int count : {sc.n_spheres, sc.n_planes, sc.n_tris, sc.n_boxes, sc.n_quads, sc.n_disks})
     if (count > kIdMask) { err = "the queue pipeline indexes at most 2^28 primitives of one type"; return RTX_ERR_UNSUPPORTED; }
   // Pool size: enough slots to keep every work item in flight if memory allows (RTX_POOL_MULT slots per resident lane at most,
   // kWfArrays * 4 bytes each: 5.4 GB for a 1080p frame at 64 spp).  A device that cannot give that much - shared, or holding a large
   // scene - gets a pool of half the size, and so on down to 16 slots per lane (measured on the 10 M-triangle frame: 128: 721 ms, 32:
   // 762, 16: 839); the environment variable RTX_POOL_MULT caps the first try.
-  if (!pool.control.ensure(sizeof(WfShared)) || !pool.queues.ensure((size_t)items * 3 * sizeof(float))) { err = "pool allocation (chunk sums)"; return RTX_ERR_OUT_OF_MEMORY; }
+  if (!pool.control.ensure(sizeof(WfShared)) || !pool.queues.ensure((size_t)all_items * 3 * sizeof(float))) { err = "pool allocation (chunk sums)"; return RTX_ERR_OUT_OF_MEMORY; }
   unsigned long long mult = (unsigned long long)RTX_POOL_MULT;
   if (const char* e = getenv("RTX_POOL_MULT")) { const long v = atol(e); if (v >= 1 && (unsigned long long)v < mult) mult = (unsigned long long)v; }
   uint32_t n_slots = 0;

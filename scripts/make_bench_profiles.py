@@ -1,5 +1,6 @@
 """Turns the scripts/profile.sh summaries under gpurun_out/prof_<config>/ into profiles/bench_profiles.json, the file bench.py
-takes its counter-derived roofline figures from, and copies each summary to profiles/r02_prof_<config>.json.
+takes its counter-derived roofline figures from, and copies each summary (and its rocprofv3 kernel statistics) to
+profiles/r03_prof_<config>.json (+ _kernel_stats.csv).
 
   python scripts/make_bench_profiles.py [c2 c3 c5]
 Every entry names the workload and the SHA-256 of the library that was profiled; bench.py uses an entry only when both match
@@ -37,8 +38,11 @@ for cfg in (sys.argv[1:] or ["c2", "c3", "c5"]):
         "SQ_INSTS_VALU": c["SQ_INSTS_VALU"] / renders, "hbm_bytes_per_launch": d.get("hbm_bytes_scattered_64B" if cfg == "c5" else "hbm_bytes", 0.0) / renders or None,
         "hbm_bytes_rule": "FETCH_SIZE as tallied (64-byte requests: scattered 64-byte records) + WRITE_SIZE" if cfg == "c5" else "2 x FETCH_SIZE (128-byte requests tallied at 64) + WRITE_SIZE",
         "lanes_active": d.get("lanes_active"), "valu_busy": d.get("valu_busy"), "valu_dual_issue_share": d.get("valu_dual_issue_share"), "l2_hit_rate": d.get("l2_hit_rate"), "kernel_ms_rocprof": e.get("ms_per_render"),
-        "source": f"profiles/r02_prof_{cfg}.json (rocprofv3 --kernel-trace --stats and separate --pmc passes of: bench.py {s.get('bench_args')})",
+        "source": f"profiles/r03_prof_{cfg}.json (rocprofv3 --kernel-trace --stats and separate --pmc passes of: bench.py {s.get('bench_args')})",
     }
-    shutil.copy(src, os.path.join(ROOT, "profiles", f"r02_prof_{cfg}.json"))
+    shutil.copy(src, os.path.join(ROOT, "profiles", f"r03_prof_{cfg}.json"))
+    import glob
+    for ks in glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{cfg}", "trace", "*", "*_kernel_stats.csv"))[:1]:
+        shutil.copy(ks, os.path.join(ROOT, "profiles", f"r03_prof_{cfg}_kernel_stats.csv"))
     print(cfg, json.dumps(allp[cfg])[:400])
 json.dump(allp, open(dst, "w"), indent=1)

@@ -92,3 +92,28 @@ def test_c5_full_size_properties(pkg, c5, c5_tracer):
     for k, n in ((5, 8), (1, 2)):
         pt.set_settings(sd.settings(shard_index=k, shard_count=n, **base))
         assert np.array_equal(pt.render().view(np.uint32), film[k::n].view(np.uint32)), (k, n)
+
+
+def test_c5_first_frame_does_not_wait_for_the_reference_order_tree(pkg, c5):
+    """rtx_upload_scene returns before the reference-order tree of a scene this size is built; a frame rendered at once decides
+    exact ties in t by primitive number, notes the work items they occur in, and renders those again when the tree is there: the
+    film equals the one rendered with the tree, bit for bit."""
+    import time
+    abi = pkg.abi
+    sd = c5["scene"]
+    W, H, spp = 1920, 1080, 8
+    with pkg.renderer.HipPathTracer(0) as pt:
+        t0 = time.perf_counter()
+        pt.upload_scene(sd)
+        upload_s = time.perf_counter() - t0
+        pt.set_camera(sd.camera(W, H))
+        pt.set_settings(sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=8, seed=1234))
+        first = pt.render().copy()
+        f1 = pt.last_stats.flags
+        info = pt.bvh_info()                       # waits for the tree (if the frame has not already)
+        second = pt.render().copy()
+        f2 = pt.last_stats.flags
+    record_rate("c5_upload_before_tree", upload_seconds=upload_s, reference_tree_seconds=float(info.build_seconds), first_frame_flags=int(f1))
+    assert f1 & abi.STAT_BEFORE_TREE and not f1 & abi.STAT_RENDERED_TWICE and f2 == 0
+    assert np.array_equal(first.view(np.uint32), second.view(np.uint32))
+    assert upload_s < info.build_seconds + 0.25    # the call did not include the tree (0.14 s against 0.39 s measured)
