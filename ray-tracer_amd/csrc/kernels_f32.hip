@@ -1,4 +1,6 @@
 // Single-precision instantiations: the production kernels.
+#include <cstdio>
+
 #include "pt_kernels.hpp"
 #include "pt_bdpt.hpp"
 #include "pt_photon_kernel.hpp"
@@ -104,6 +106,18 @@ int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, cons
     hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, false>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
   else
     return -1;
+#ifdef RTX_PHASE_STATS
+  {
+    unsigned long long h[32];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_stats), sizeof h);
+    fprintf(stderr, "phase stats:");
+    for (int b = 0; b < 14; ++b) fprintf(stderr, " %d:%llu/%llu", b, h[2 * b], h[2 * b + 1]);
+    fprintf(stderr, "\n");
+    for (auto& v : h) v = 0ull;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_stats), h, sizeof h);
+  }
+#endif
   return 0;
 }
 

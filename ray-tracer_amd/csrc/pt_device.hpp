@@ -1164,6 +1164,15 @@ namespace rtx {
 
 // What one vertex did, for the statistics: bit 0 = a shadow ray was cast, bit 1 = the vertex was shaded.
 enum : uint32_t { STEP_SHADOW = 1u, STEP_SHADED = 2u, STEP_TIED = 4u };   // TIED: the vertex's closest-hit query decided a tie without the reference's order
+// Diagnostic build (-DRTX_PHASE_STATS, never shipped): which branches of the vertex a lane took, so that the fused kernel can count
+// how often a WAVE pays for each of them (scripts/phase_table.py weights the static instruction counts with these frequencies).
+enum : uint32_t { STEP_X_SETTLE = 8u, STEP_X_MISS = 16u, STEP_X_AREA = 32u, STEP_X_LAMBERT = 64u, STEP_X_METAL = 128u, STEP_X_GLASS = 256u, STEP_X_ROULETTE = 512u,
+                  STEP_X_LIGHT_SAMPLE = 1024u, STEP_X_DEPTH = 2048u };
+#ifdef RTX_PHASE_STATS
+#define RTX_PHASE(bit) (did |= (bit))
+#else
+#define RTX_PHASE(bit) ((void)0)
+#endif
 
 // Shade the vertex a trace of ps.ray found (`hit`, `rec`): settle the previous vertex's pending
 // MIS term, add emission, sample a light, scatter, Russian roulette.  The visibility query of
@@ -1190,6 +1199,7 @@ RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, Hit<R>& rec,
       if (rec.mat >= 0) {
         const DMaterial<R>& nm = mats[rec.mat];
         if (is_emissive(nm)) {
+          RTX_PHASE(STEP_X_SETTLE);
           R cl = abs_(dot(rec.n, -ps.ray.d));
           R lpa = light_pdf(sc, rec.p);
           if (lpa > R(0) && cl > R(0)) {
@@ -1205,9 +1215,10 @@ RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, Hit<R>& rec,
       if (ep > R(0)) { R w = power_heuristic(ps.bsdf_pdf, ep); ps.acc = ps.acc + (ps.thr * ee) * w; }
     }
   }
-  if (bounce >= P.max_depth) { ps.bounce_flags = 0; return did; }
+  if (bounce >= P.max_depth) { RTX_PHASE(STEP_X_DEPTH); ps.bounce_flags = 0; return did; }
 
   if (!hit) {  // ref: engine/renderer.cpp:591-606
+    RTX_PHASE(STEP_X_MISS);
     bool handled = nee && mis && was_diffuse && env_is;
     if (!handled) ps.acc = ps.acc + ps.thr * background(sc, P, ps.ray);
     ps.bounce_flags = 0;
@@ -1215,6 +1226,7 @@ RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, Hit<R>& rec,
   }
   did |= STEP_SHADED;
   if (rec.mat < 0) {  // area light, ref: engine/renderer.cpp:609-630
+    RTX_PHASE(STEP_X_AREA);
     V3<R> Le = area_light_emission(sc, rec.mat);
     if (bounce == 0 || was_spec || !nee) {
       ps.acc = ps.acc + ps.thr * Le;
@@ -1242,7 +1254,9 @@ RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, Hit<R>& rec,
   const U4 rn = rng_block(key.rng, key.pixel, key.seed, key.sample, 1u + (uint32_t)bounce);
 
   if (m.type == MAT_LAMBERTIAN) {
+    RTX_PHASE(STEP_X_LAMBERT);
     if (nee) {  // ref: engine/renderer.cpp:654-714
+      RTX_PHASE(STEP_X_LIGHT_SAMPLE);
       bool skip_mnee = false;
       LightPick<R> ls = sample_light(sc, mats, rec.p, u16hi<R>(rn.z), u16hi<R>(rn.x), u16lo<R>(rn.x));
       if (ls.valid) {
@@ -1287,12 +1301,14 @@ RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, Hit<R>& rec,
     bsdf_pdf = dot(rec.n, sdir) / Consts<R>::pi;
     flags |= F_DIFFUSE;
   } else if (m.type == MAT_METAL) {  // ref: engine/renderer.cpp:747-759 (below-surface directions continue)
+    RTX_PHASE(STEP_X_METAL);
     bool spec = true;
     V3<R> refl = reflect(normalize(ps.ray.d), rec.n);
     if (m.fuzz > R(0)) { refl = refl + unit_vector(u16hi<R>(rn.y), u16lo<R>(rn.y)) * m.fuzz; spec = m.fuzz < R(0.1); }
     sdir = refl;
     if (spec) flags |= F_SPEC;
   } else {  // dielectric, ref: engine/renderer.cpp:761-778
+    RTX_PHASE(STEP_X_GLASS);
     flags |= F_SPEC;
     atten = {R(1), R(1), R(1)};
     R ratio = rec.front ? (R(1) / m.ior) : m.ior;
@@ -1318,6 +1334,7 @@ RTX_DEV uint32_t path_vertex_impl(PathState<R>& ps, const bool hit, Hit<R>& rec,
   }
 #else
   if (bounce > 3) {
+    RTX_PHASE(STEP_X_ROULETTE);
     R p = max_(ps.thr.x, max_(ps.thr.y, ps.thr.z));
     killed = p < R(0.01) || u16lo<R>(rn.z) > p;
     R boost = killed ? R(1) : R(1) / p;

@@ -72,6 +72,9 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #ifndef RTX_MNEE_MIN_WAVES
 #define RTX_MNEE_MIN_WAVES 3   // manifold NEE instance (double precision): measured 1: 330 ms, 2: 240, 3: 219, 4: 263 (cornell_box_quad 800x800x16)
 #endif
+#ifdef RTX_PHASE_STATS
+static __device__ unsigned long long g_phase_stats[32];   // diagnostic build only: (wave-trips, lanes) per STEP_* bit
+#endif
 // LEAN (bit mask) compiles scene features out of an instance by pinning the scene's counts to zero, so that every
 // branch on them folds away: 1 = no environment map, 2 = no point and no disk lights, 4 = no quad lights,
 // 8 = NEE and MIS on, 16 = the pcg4d generator, 32 = no material has a normal map (the tangent-frame code is left out),
@@ -182,6 +185,15 @@ __global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4
       if constexpr (MODE != MODE_FLAT && sizeof(R) == 4) { if (did & STEP_TIED) note_tied_item(P, counters, cur); }
       w_shadow += (uint32_t)__popcll(__ballot((did & STEP_SHADOW) != 0));
       w_shaded += (uint32_t)__popcll(__ballot((did & STEP_SHADED) != 0));
+#ifdef RTX_PHASE_STATS
+      {   // per phase: wave-trips in which some lane took it, and the lanes that did (slot 12: all trips; 13: paths that ended)
+        const uint32_t bits = did | (1u << 12) | ((ps.bounce_flags & F_ALIVE) ? 0u : (1u << 13));
+        for (int b = 0; b < 14; ++b) {
+          const unsigned long long m = __ballot((bits >> b) & 1u);
+          if ((threadIdx.x & 63) == 0 && m) { atomicAdd(&g_phase_stats[2 * b], 1ull); atomicAdd(&g_phase_stats[2 * b + 1], (unsigned long long)__popcll(m)); }
+        }
+      }
+#endif
       bool started = false;
       if (!(ps.bounce_flags & F_ALIVE)) {
         sum = sum + ps.acc;
