@@ -42,8 +42,8 @@ int launch_render_bdpt(const DScene<float>& sc, const DCamera<float>& cam, const
   return 0;
 }
 
-int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
-                        const FusedLaunch& L, hipStream_t stream) {
+static int launch_render_fused_instance(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
+                                        const FusedLaunch& L, hipStream_t stream) {
   dim3 g(L.grid), b(kBlock);
   if (L.integ == INTEG_PATHPHOTON) {   // the flat instance or the general (TREE_UV) ones
     if (L.mode == MODE_FLAT && L.lds_mats) {
@@ -106,19 +106,25 @@ int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, cons
     hipLaunchKernelGGL((render_fused_kernel<float, MODE_TREE_UV, false>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
   else
     return -1;
+  return 0;
+}
+
+int launch_render_fused(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters,
+                        const FusedLaunch& L, hipStream_t stream) {
+  const int rc = launch_render_fused_instance(sc, cam, P, partial, counters, L, stream);
 #ifdef RTX_PHASE_STATS
   {
-    unsigned long long h[32];
+    unsigned long long h[64];
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_stats), sizeof h);
     fprintf(stderr, "phase stats:");
-    for (int b = 0; b < 14; ++b) fprintf(stderr, " %d:%llu/%llu", b, h[2 * b], h[2 * b + 1]);
+    for (int b = 0; b < 32; ++b) if (h[2 * b]) fprintf(stderr, " %d:%llu/%llu", b, h[2 * b], h[2 * b + 1]);
     fprintf(stderr, "\n");
     for (auto& v : h) v = 0ull;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_stats), h, sizeof h);
   }
 #endif
-  return 0;
+  return rc;
 }
 
 void launch_film_reduce(const float* partial, float* film, unsigned long long npix, int n_chunks, int spp, hipStream_t stream) {

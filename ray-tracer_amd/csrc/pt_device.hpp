@@ -1114,6 +1114,28 @@ template <bool UNIT = false> RTX_DEV bool flat_occluded(const DScene<float>& sc,
   return any;
 }
 
+// Is any primitive of material `mat` (>= 0: area lights carry negative ids) hit in [t_min, t_max] at all?  When the answer is no,
+// the closest hit of that ray - if it has one - belongs to another material, and a caller that only asks "is the closest hit of
+// material mat" (the re-projection of manifold NEE) need not make the query.  The tests are flat_closest_tk's, against the whole
+// interval instead of the shrinking one, so a primitive that could win there is never missed here.  A primitive is tested only if
+// some lane of the wave asks for its material (its record is wave-uniform): one sphere test where the closest-hit query makes
+// eight.
+RTX_DEV bool flat_hits_material(const DScene<float>& sc, const Ray<float>& r, float t_min, float t_max, int mat) {
+  const float a = len2(r.d), inv_a = rcp_(a);
+  float t;
+  bool any = false;
+  int n = 0;
+  for (int i = 0; i < sc.n_prims; ++i, ++n) {
+    const bool mine = sc.flat[n].mat == mat;
+    if (__ballot(mine)) any |= mine && flat_sphere_t(sc.spheres[sc.prims[i].index], r, a, inv_a, t_min, t_max, t);
+  }
+  for (int i = 0; i < sc.n_planes; ++i, ++n) {
+    const bool mine = sc.flat[n].mat == mat;
+    if (__ballot(mine)) any |= mine && flat_plane_pd(sc.planes[i].n, sc.planes[i].pd, r, t_min, t_max, t);
+  }
+  return any;
+}
+
 // How a kernel instance intersects: MODE_FLAT (float, small sphere-only scenes, no image
 // textures), MODE_TREE (anything: production BVH / linear list, exact operand order in double).
 template <class R, int MODE> RTX_DEV bool trace_closest(const DScene<R>& sc, const Ray<R>& r, R t_min, R t_max, Hit<R>& h, LaneStack st) {
@@ -1158,6 +1180,18 @@ template <class R> RTX_DEV void path_begin(PathState<R>& ps, const DCamera<R>& c
   ps.bounce_flags = F_ALIVE;
 }
 
+#ifdef RTX_PHASE_STATS
+// Diagnostic build only (never shipped).  Slots 0..13: (wave-trips, lanes) per STEP_* bit of the fused kernel's loop; from 16 on:
+// RTX_SITE(k) counts, wherever it stands, the times a wave passed and the lanes that were active.
+static __device__ unsigned long long g_phase_stats[64];
+#define RTX_SITE(k)                                                                                                                       \
+  {                                                                                                                                       \
+    const unsigned long long m_ = __ballot(1);                                                                                            \
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { atomicAdd(&g_phase_stats[2 * (k)], 1ull); atomicAdd(&g_phase_stats[2 * (k) + 1], (unsigned long long)__popcll(m_)); } \
+  }
+#else
+#define RTX_SITE(k)
+#endif
 }  // namespace rtx
 #include "pt_mnee.hpp"
 namespace rtx {
@@ -1418,6 +1452,28 @@ RTX_DEV uint32_t whitted_vertex(PathState<R>& ps, const bool hit, Hit<R>& rec, c
 #include "pt_photon.hpp"
 namespace rtx {
 
+// The closest-hit queries of manifold NEE (pt_mnee.hpp): Scene::hit through this kernel instance's structures, counted.
+template <class R, int MODE> struct MneeTracer {
+  const DScene<R>& sc;
+  LaneStack st;
+  uint32_t& queries;
+  RTX_DEV bool operator()(const Ray<R>& r, R t_min, R t_max, Hit<R>& h) {
+    ++queries;
+    return trace_closest<R, MODE>(sc, r, t_min, t_max, h, st);
+  }
+  // A query whose only question is "does the closest hit have material mat": false = it certainly has not, and the query counts
+  // as made; true = undecided, make it.  (Decided here for single-precision flat scenes only.)
+  RTX_DEV bool may_hit_material(const Ray<R>& r, R t_min, R t_max, int mat) {
+    if constexpr (MODE == MODE_FLAT && std::is_same<R, float>::value) {
+      if (flat_hits_material(sc, r, t_min, t_max, mat)) return true;
+      ++queries;
+      return false;
+    } else {
+      return true;
+    }
+  }
+};
+
 // Fused form: trace, shade, and trace the shadow ray(s) in place.  `extra_traces` counts the closest-hit
 // queries MNEE makes, `extra_shadow` the shadow queries of the Whitted integrator.
 template <class R, int MODE, int INTEG = INTEG_PATH, bool NMAP = (MODE == MODE_TREE_UV)>
@@ -1440,10 +1496,7 @@ RTX_DEV uint32_t path_step(PathState<R>& ps, const DScene<R>& sc, const DMateria
           return visible;
         },
         [&](V3<R> hp, V3<R> surf, int bounce) {   // MNEE::evaluate on the spot (ref: engine/renderer.cpp:716-732)
-          auto trace = [&](const Ray<R>& r, R t_min, R t_max, Hit<R>& h) {
-            ++extra_traces;
-            return trace_closest<R, MODE>(sc, r, t_min, t_max, h, st);
-          };
+          MneeTracer<R, MODE> trace = {sc, st, extra_traces};
           V3<R> mc;
           if (mnee_evaluate(sc, mats, hp, key, bounce, mc, trace)) {
             V3<R> md = ((mc * surf) * ps.thr) * (R(1) / R(3.14159265358979323846));

@@ -67,13 +67,10 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #define RTX_PHOTON_FLAT_MIN_WAVES 4   // PathPhoton on a flat scene
 #endif
 #ifndef RTX_MNEE_F32_MIN_WAVES
-#define RTX_MNEE_F32_MIN_WAVES 3   // manifold NEE instances with single-precision traces (measured on the 1080p Cornell box: 1: 50.9 Msamples/s, 2: 75.6, 3: 82.5, 4: 77.1)
+#define RTX_MNEE_F32_MIN_WAVES 4   // manifold NEE instances with single-precision traces (measured on the 1080p Cornell box, 16 spp: 2: 342 ms, 3: 301, 4: 288, 5: 421)
 #endif
 #ifndef RTX_MNEE_MIN_WAVES
 #define RTX_MNEE_MIN_WAVES 3   // manifold NEE instance (double precision): measured 1: 330 ms, 2: 240, 3: 219, 4: 263 (cornell_box_quad 800x800x16)
-#endif
-#ifdef RTX_PHASE_STATS
-static __device__ unsigned long long g_phase_stats[32];   // diagnostic build only: (wave-trips, lanes) per STEP_* bit
 #endif
 // LEAN (bit mask) compiles scene features out of an instance by pinning the scene's counts to zero, so that every
 // branch on them folds away: 1 = no environment map, 2 = no point and no disk lights, 4 = no quad lights,

@@ -75,14 +75,30 @@ template <class S, class R, class Trace> RTX_DEV bool mnee_trace(const DScene<R>
   return true;
 }
 
-template <class R> RTX_DEV void mnee_frame(V3<R> n, V3<R>& t, V3<R>& b) {   // ref: mnee.hpp:299-304
+// normalize() of the solver's inner loop.  FAST (the single-precision production mode, where the walk's doubles need not equal
+// the reference's bit for bit): 1 / |v| from the hardware's reciprocal square root estimate and two Newton steps, full double
+// precision for the lengths that occur here (1e-3 to 1e2: no rescaling), a third of the instructions of sqrt followed by a
+// division.  Otherwise the reference's v / sqrt(v . v).
+template <bool FAST, class R> RTX_DEV V3<R> mnee_normalize(V3<R> v) {
+  if constexpr (FAST && std::is_same<R, double>::value) {
+    const double l2 = len2(v);
+    double y = __builtin_amdgcn_rsq(l2);
+    y = fma(0.5 * y, fma(-l2 * y, y, 1.0), y);
+    y = fma(0.5 * y, fma(-l2 * y, y, 1.0), y);
+    return l2 > 0.0 ? v * y : v;
+  } else {
+    return normalize(v);
+  }
+}
+
+template <bool FAST = false, class R> RTX_DEV void mnee_frame(V3<R> n, V3<R>& t, V3<R>& b) {   // ref: mnee.hpp:299-304
   V3<R> up = (abs_(n.y) < R(0.9)) ? V3<R>{R(0), R(1), R(0)} : V3<R>{R(1), R(0), R(0)};
-  t = normalize(cross(up, n));
+  t = mnee_normalize<FAST>(cross(up, n));
   b = cross(n, t);
 }
 
-template <class R> RTX_DEV void mnee_constraint(V3<R> prev, V3<R> cur, V3<R> next, R eta, V3<R> t, V3<R> b, R& cu, R& cv) {   // ref: mnee.hpp:328-347
-  V3<R> wi = normalize(prev - cur), wo = normalize(next - cur);
+template <bool FAST = false, class R> RTX_DEV void mnee_constraint(V3<R> prev, V3<R> cur, V3<R> next, R eta, V3<R> t, V3<R> b, R& cu, R& cv) {   // ref: mnee.hpp:328-347
+  V3<R> wi = mnee_normalize<FAST>(prev - cur), wo = mnee_normalize<FAST>(next - cur);
   R wi_u = dot(wi, t), wi_v = dot(wi, b), wo_u = dot(wo, t), wo_v = dot(wo, b);
   cu = eta * wi_u + wo_u; cv = eta * wi_v + wo_v;
 }
@@ -91,10 +107,16 @@ template <class S, class R, class Trace> RTX_DEV bool mnee_reproject(const DScen
   Hit<R> rec;
   V3<S> hp, hn;
   for (int d = 0; d < 2; ++d) {
+    if (d == 0) { RTX_SITE(18) } else { RTX_SITE(19) }
+    // The first probe leaves the surface it should find in nineteen of twenty cases (a Newton step moves the vertex along the
+    // tangent plane, i.e. off a convex surface on its outer side): ask first whether it can meet that material at all.
+    if (d == 0 && !trace.may_hit_material(Ray<R>{v3_to<R>(pos), v3_to<R>(n)}, R(0), R(0.1), expected)) continue;
+    if (d == 0) { RTX_SITE(26) }
     if (mnee_trace(sc, pos, d == 0 ? n : -n, S(0), S(0.1), rec, hp, hn, trace)) {
       if (rec.mat == expected) { pos = hp; n = hn; return true; }
     }
   }
+  RTX_SITE(20)
   if (mnee_trace(sc, pos + n * S(0.05), -n, S(0), S(0.2), rec, hp, hn, trace)) {
     if (rec.mat == expected) { pos = hp; n = hn; return true; }
   }
@@ -146,32 +168,37 @@ template <class R, class SR, class Trace> RTX_DEV bool mnee_build_path(const DSc
 template <class R, class SR, class Trace> RTX_DEV bool mnee_solve(const DScene<SR>& sc, V3<R> sp, V3<R> lp, MChain<R>& ch, int n, R& throughput, Trace& trace) {
   // (the reference keeps every vertex's tangent frame in an array and renews it after the vertex's re-projection; a frame is a
   // function of the vertex's normal alone, so it is computed where it is used: the same values, a dozen registers fewer per vertex)
+  constexpr bool kFast = !mnee_same<R, SR>::value;
   for (int iter = 0; iter < kMneeMaxIter; ++iter) {
+    RTX_SITE(16)
     R max_c = R(0);
     R c_u0 = R(0), c_u1 = R(0), c_u2 = R(0), c_u3 = R(0), c_v0 = R(0), c_v1 = R(0), c_v2 = R(0), c_v3 = R(0);   // cu[i], cv[i]
     for (int i = 0; i < n; ++i) {
       const MVertex<R> vi = ch.get(i);
       V3<R> prev = (i == 0) ? sp : ch.p(i - 1), next = (i == n - 1) ? lp : ch.p(i + 1);
       V3<R> tg, bt;
-      mnee_frame(vi.n, tg, bt);
+      mnee_frame<kFast>(vi.n, tg, bt);
       R cu, cv;
-      mnee_constraint(prev, vi.p, next, vi.eta, tg, bt, cu, cv);
+      mnee_constraint<kFast>(prev, vi.p, next, vi.eta, tg, bt, cu, cv);
       if (i == 0) { c_u0 = cu; c_v0 = cv; } else if (i == 1) { c_u1 = cu; c_v1 = cv; } else if (i == 2) { c_u2 = cu; c_v2 = cv; } else { c_u3 = cu; c_v3 = cv; }
       R mag = sqrt_(cu * cu + cv * cv);
       max_c = max_(max_c, mag);
     }
-    if (max_c < R(1e-6)) return mnee_build_path(sc, sp, lp, ch, n, throughput, trace);
+    if (max_c < R(1e-6)) { RTX_SITE(21) return mnee_build_path(sc, sp, lp, ch, n, throughput, trace); }
     for (int i = 0; i < n; ++i) {
+      RTX_SITE(17)
       MVertex<R> vi = ch.get(i);
       V3<R> prev = (i == 0) ? sp : ch.p(i - 1), next = (i == n - 1) ? lp : ch.p(i + 1);
       V3<R> tg, bt;
-      mnee_frame(vi.n, tg, bt);
+      mnee_frame<kFast>(vi.n, tg, bt);
       const R cu_i = i == 0 ? c_u0 : i == 1 ? c_u1 : i == 2 ? c_u2 : c_u3, cv_i = i == 0 ? c_v0 : i == 1 ? c_v1 : i == 2 ? c_v2 : c_v3;
       const R h = R(1e-5);
       R c0u, c0v, cuu, cuv, cvu, cvv;
-      mnee_constraint(prev, vi.p, next, vi.eta, tg, bt, c0u, c0v);
-      mnee_constraint(prev, vi.p + tg * h, next, vi.eta, tg, bt, cuu, cuv);
-      mnee_constraint(prev, vi.p + bt * h, next, vi.eta, tg, bt, cvu, cvv);
+      // (the first vertex's neighbours have not moved since the residuals above were taken: the same operands, the same values)
+      if (i == 0) { c0u = c_u0; c0v = c_v0; }
+      else mnee_constraint<kFast>(prev, vi.p, next, vi.eta, tg, bt, c0u, c0v);
+      mnee_constraint<kFast>(prev, vi.p + tg * h, next, vi.eta, tg, bt, cuu, cuv);
+      mnee_constraint<kFast>(prev, vi.p + bt * h, next, vi.eta, tg, bt, cvu, cvv);
       R J00 = (cuu - c0u) / h, J01 = (cvu - c0u) / h, J10 = (cuv - c0v) / h, J11 = (cvv - c0v) / h;
       R b0 = -cu_i, b1 = -cv_i, st0, st1;
       R det = J00 * J11 - J01 * J10;
@@ -200,6 +227,7 @@ template <class R, class SR, class Trace> RTX_DEV int mnee_straight_chain(const 
     Hit<SR> rec;
     V3<R> hp, hn;
     R max_t = len(lp - cur) - R(1e-6);
+    RTX_SITE(25)
     if (!mnee_trace(sc, probe_o, dir, R(0.001), max_t, rec, hp, hn, trace)) break;
     // a quad / disk light in the way has a negative id (the reference indexes its material
     // array with it: undefined behaviour); defined here as "not a dielectric"
@@ -275,7 +303,8 @@ template <class R, class SR, class Trace> RTX_DEV bool mnee_connect(const DScene
       n = mnee_sphere_seed_chain(sph, m, sp, lp, ch);
     }
     if (n == 0) continue;
-    if (mnee_solve(sc, sp, lp, ch, n, throughput, trace)) return true;
+    RTX_SITE(22)
+    if (mnee_solve(sc, sp, lp, ch, n, throughput, trace)) { RTX_SITE(24) return true; }
   }
   return false;
 }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B timing of library builds on one box: renders a configuration with each shared library given (paths; "-" = the tree's own)
 through the handful of entry points every build has, so that older builds can be compared too.
-Usage: python scripts/ab_render.py c2|c5 [spp] -- lib1 lib2 ...      One JSON line per library, best of three renders."""
+Usage: python scripts/ab_render.py c2|c2mnee|c5 [spp] -- lib1 lib2 ...      One JSON line per library, best of three renders.
+(c2mnee: the Cornell box with use_mnee = 1, 16 spp.)"""
 import ctypes as C
 import json
 import os
@@ -20,14 +21,15 @@ spp = int(args[1]) if split > 1 else 0
 if cfg == "c5":
     sd, (W, H, SPP, depth) = pkg.synthetic.stress_scene(10_000_000), (1920, 1080, 64, 8)
 else:
-    sd, (W, H, SPP, depth) = pkg.scene_loader.load(os.path.join(ROOT, "tests", "golden", "scenes", "cornell_box.json")), (1920, 1080, 1024, 500)
+    sd, (W, H, SPP, depth) = pkg.scene_loader.load(os.path.join(ROOT, "tests", "golden", "scenes", "cornell_box.json")), (1920, 1080, 16 if cfg == "c2mnee" else 1024, 500)
 spp = spp or SPP
 abi._share_torch_hip_runtime()
 import torch  # noqa: E402
 out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
 desc = sd.desc()
 cam = sd.camera(W, H)
-st = sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=depth, use_nee=1, use_mis=1, seed=1234, mode=abi.MODE_PATHTRACE, precision=abi.PRECISION_F32)
+st = sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=depth, use_nee=1, use_mis=1, seed=1234, mode=abi.MODE_PATHTRACE, precision=abi.PRECISION_F32,
+                 use_mnee=1 if cfg == "c2mnee" else 0)
 first = None
 for path in libs:
     p = abi.LIB_PATH if path == "-" else os.path.join(ROOT, path)
