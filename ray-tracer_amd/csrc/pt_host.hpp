@@ -152,6 +152,7 @@ struct FusedLaunch {
   size_t lds_bytes;     // dynamic LDS per workgroup
   int stack_first_int;  // offset (in ints) of the traversal stacks inside the dynamic LDS
   int integ = INTEG_PATH;  // INTEG_*: path tracing, path tracing with MNEE (double precision only), Whitted (TREE_UV instances only)
+  bool mnee_batched = true;   // single-precision manifold NEE: the solves of a wave batched (render_fused_mnee_batched_kernel); RTX_MNEE_ON_THE_SPOT=1 in the environment launches the instance that solves at the vertex
   int regroup = 0;         // experiment (RTX_FUSED_REGROUP): > 0 launches the material-coherent variant of the lean flat path tracer; lanes trade places when a wave has at least this many lanes outside its majority class
 };
 // PathPhoton photon pass (pt_photon.hpp): `out` = 10 planes of n_photons values (position, -direction, power, valid)

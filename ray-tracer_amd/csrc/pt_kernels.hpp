@@ -226,6 +226,157 @@ __global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4
 }
 
 // ------------------------------------------------------------------------------------------
+// Manifold NEE in single precision with the solves of a wave BATCHED (INTEG_PATH_MNEE, R = float).
+// A manifold solve costs a hundred path vertices (20 Newton iterations of double-precision algebra and two closest-hit queries
+// per chain vertex), and only about half of the Lambertian vertices ask for one (the seed chain through a glass sphere is tried
+// when the sphere lies towards the light): solved on the spot, as render_fused_kernel does, a solve runs with 30 of a wave's 64
+// lanes.  Here a vertex only looks for its first solve (pt_mnee.hpp mnee_next_attempt: the light's sample, the straight chain, the
+// seed conditions - cheap) and NOTES it (point, weight = albedo x throughput / pi, sample, bounce, light and attempt: a "task"),
+// and its lane stops; the other lanes go on with their paths - cheap trips - until kMneeBatch lanes of the wave hold a task,
+// and then the wave runs one solve for each of them at once; a task whose solve fails and which has another attempt left stays.  Nothing moves between lanes.  A task's contribution is a function of the task alone and goes to
+// an accumulator of its own (sum_mnee), added to the chunk sum when the work item ends, so the film does not depend on when the
+// wave happened to solve: launch- and shard-invariant like the other kernels'.  The solver also runs with little else alive in
+// registers (on the spot, the whole vertex is).
+// ------------------------------------------------------------------------------------------
+#ifndef RTX_MNEE_BATCH
+#define RTX_MNEE_BATCH 56   // lanes of 64 that must hold a task (1080p Cornell box, 16 spp: 32: 248 ms, 48: 211, 56: 206, 62: 212; solved on the spot: 270)
+#endif
+#ifndef RTX_MNEE_BATCHED_MIN_WAVES
+#define RTX_MNEE_BATCHED_MIN_WAVES 3   // (the same frame: 3: 197.6 ms, 4: 205.4, 5: 282.5)
+#endif
+constexpr int kMneeBatch = RTX_MNEE_BATCH;
+template <int MODE, bool LDS_MATS, int LEAN>
+__global__ __launch_bounds__(kBlock, RTX_MNEE_BATCHED_MIN_WAVES) void render_fused_mnee_batched_kernel(DScene<float> sc, DCamera<float> cam, DRenderParams P, float* __restrict__ partial,
+                                                                                                   DCounters* __restrict__ counters, int stack_first_int) {
+  using R = float;
+  if constexpr ((LEAN & 1) != 0) { sc.env.valid = 0; sc.env.importance = 0; }
+  if constexpr ((LEAN & 2) != 0) { sc.n_points = 0; sc.n_disks = 0; }
+  if constexpr ((LEAN & 4) != 0) { sc.n_quads = 0; }
+  if constexpr ((LEAN & 8) != 0) { P.use_nee = 1; P.use_mis = 1; }
+  if constexpr ((LEAN & 16) != 0) { P.rng = RNG_PCG4D; }
+  const DMaterial<R>* mats = sc.mats;
+  if constexpr (LDS_MATS) mats = stage_materials(sc);
+  const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
+  const uint32_t n_items = P.item_list ? P.n_list : npix * (uint32_t)P.n_chunks;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  uint32_t next = blockIdx.x * blockDim.x + threadIdx.x;
+  LaneStack st = lane_stack(stack_first_int);
+  uint32_t w_steps = 0, w_shadow = 0, w_shaded = 0, w_samples = 0, extra_traces = 0;
+  PathState<R> ps;
+  ps.ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}}; ps.thr = {0.f, 0.f, 0.f}; ps.acc = {0.f, 0.f, 0.f}; ps.bsdf_pdf = 0.f;
+  ps.bounce_flags = 0;
+  V3<R> sum = {0.f, 0.f, 0.f}, sum_mnee = {0.f, 0.f, 0.f};
+  uint32_t cur = 0, xy = 0;
+  int s = 0, s_end = 0;
+  PathKey key = {0u, P.seed, 0u, (uint32_t)P.rng};
+  // the lane's task
+  bool pending = false, finishing = false;   // finishing: the work item's last path has ended, its chunk sum waits for the task
+  V3<R> task_p = {0.f, 0.f, 0.f}, task_w = {0.f, 0.f, 0.f};
+  uint32_t task_sample = 0u;
+  int task_bounce = 0, task_j = 0, task_i = -1;   // the attempt to run: light j, chain i (pt_mnee.hpp)
+  uint32_t quiet_queries = 0u;
+
+  auto fetch = [&]() -> bool {
+    if (next >= n_items) return false;
+    cur = P.item_list ? P.item_list[next] : next;
+    next += stride;
+    uint32_t chunk = cur / npix;
+    uint32_t pix = cur - chunk * npix;
+    uint32_t row_local = pix / (uint32_t)P.width;
+    uint32_t x = pix - row_local * (uint32_t)P.width;
+    uint32_t y = (uint32_t)P.shard_index + row_local * (uint32_t)P.shard_count;
+    xy = (y << 16) | x;
+    key.pixel = y * (uint32_t)P.width + x;
+    s = (int)chunk * P.chunk_spp;
+    s_end = s + P.chunk_spp < P.spp ? s + P.chunk_spp : P.spp;
+    sum = {0.f, 0.f, 0.f}; sum_mnee = {0.f, 0.f, 0.f};
+    return s < s_end;
+  };
+  auto store_item = [&]() {
+    R* o = partial + (size_t)cur * 3u;
+    o[0] = sum.x + sum_mnee.x; o[1] = sum.y + sum_mnee.y; o[2] = sum.z + sum_mnee.z;
+  };
+
+  bool active = fetch();
+  if (active) { key.sample = (uint32_t)s++; path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key); }
+  w_samples += (uint32_t)__popcll(__ballot(active));
+  for (;;) {
+    // 1. solve, when enough lanes hold a task or no lane can do anything else
+    const int n_pending = __popcll(__ballot(pending)), n_active = __popcll(__ballot(active));
+    if (n_active == 0) break;
+    const bool someone_can_go = __ballot(active && !pending) != 0ull;
+    if (n_pending > 0 && (n_pending * 64 >= kMneeBatch * n_active || !someone_can_go)) {
+      bool started = false;
+      if (pending) {
+        PathKey tk = key;
+        tk.sample = task_sample;
+        MneeTracer<R, MODE> trace = {sc, st, extra_traces}, quiet = {sc, st, quiet_queries};
+        const V3<double> hp = v3_to<double>(task_p);
+        V3<double> c;
+        if (mnee_run_attempt(sc, mats, hp, tk, task_bounce, task_j, task_i, c, trace, quiet)) {   // MNEE::evaluate (ref: engine/renderer.cpp:716-732), one solve of it
+          sum_mnee = sum_mnee + v3_to<R>(c) * task_w;
+          ++task_j; task_i = -1;
+        } else {
+          ++task_i;
+        }
+        pending = mnee_next_attempt(sc, mats, hp, tk, task_bounce, task_j, task_i, trace);
+        if (!pending && finishing) {
+          finishing = false;
+          store_item();
+          active = fetch();
+          if (active) { key.sample = (uint32_t)s++; path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key); started = true; }
+        }
+      }
+      w_samples += (uint32_t)__popcll(__ballot(started));
+      continue;
+    }
+    // 2. one vertex for every lane that has a path and no task
+    const bool go = active && !pending;
+    uint32_t did = 0u;
+    bool started = false;
+    if (go) {
+      Hit<R> rec;
+      const bool hit = trace_closest<R, MODE>(sc, ps.ray, 0.001f, 1e9f, rec, st);
+      if constexpr (MODE != MODE_FLAT) { if (hit && rec.tied) note_tied_item(P, counters, cur); }
+      did = path_vertex_impl<R, true, MODE == MODE_TREE_UV && (LEAN & 32) == 0>(
+          ps, hit, rec, sc, mats, P, key,
+          [&](const Ray<R>& sr, R t_max, V3<R> contrib) {
+            const bool visible = !trace_occluded<R, MODE, true>(sc, sr, 0.001f, t_max, st);
+            if (visible) ps.acc = ps.acc + contrib;
+            return visible;
+          },
+          [&](V3<R> hp, V3<R> surf, int bounce) {
+            task_p = hp; task_w = (surf * ps.thr) * (1.0f / 3.14159265358979323846f);
+            task_sample = key.sample; task_bounce = bounce; task_j = 0; task_i = -1;
+            MneeTracer<R, MODE> trace = {sc, st, extra_traces};
+            pending = mnee_next_attempt(sc, mats, v3_to<double>(hp), key, bounce, task_j, task_i, trace);
+          });
+      if (!(ps.bounce_flags & F_ALIVE)) {
+        sum = sum + ps.acc;
+        bool more = true;
+        if (s == s_end) {
+          if (pending) { finishing = true; more = false; }
+          else { store_item(); active = fetch(); more = active; }
+        }
+        if (more) { key.sample = (uint32_t)s++; path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key); started = true; }
+      }
+    }
+    w_steps += (uint32_t)__popcll(__ballot(go));
+    w_shadow += (uint32_t)__popcll(__ballot((did & STEP_SHADOW) != 0));
+    w_shaded += (uint32_t)__popcll(__ballot((did & STEP_SHADED) != 0));
+    w_samples += (uint32_t)__popcll(__ballot(started));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) extra_traces += (uint32_t)__shfl_xor((int)extra_traces, off, 64);
+  if ((threadIdx.x & 63) == 0) {   // (every lane stays to the end: the counters are the same in all of them)
+    atomicAdd(&counters->samples, (unsigned long long)w_samples);
+    atomicAdd(&counters->closest, (unsigned long long)(w_steps + extra_traces));
+    atomicAdd(&counters->shadow, (unsigned long long)w_shadow);
+    atomicAdd(&counters->segments, (unsigned long long)w_shaded);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // The same path tracer with MATERIAL-COHERENT waves (experiment, RTX_FUSED_REGROUP=1; flat scenes, plain path tracing).
 // After the closest-hit query of a trip every lane knows what its vertex needs next: a Lambertian vertex (light sample, shadow
 // query, cosine scatter), a specular one (mirror / glass), the end of its path (miss, light: the next sample starts), or

@@ -285,23 +285,25 @@ template <class R, class SR> RTX_DEV int mnee_sphere_seed_chain(const DSphere<SR
 // ref: connect_to_light, mnee.hpp:73-88, with connect_to_light_seeded, :152-189: the straight chain first, then a seed chain
 // through every dielectric sphere that lies towards the light; the first chain the solver brings to convergence wins.  (One
 // loop over the attempts, so that the solver and its closest-hit queries are instantiated once.)
+// The chain attempt i starts from: i = -1 the straight chain, i >= 0 the seed chain through sphere i.  Returns its length, 0 = the
+// attempt does not exist (nothing dielectric in the way / the sphere is no dielectric or does not lie towards the light).
+template <class R, class SR, class Trace> RTX_DEV int mnee_attempt_chain(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<R> sp, V3<R> lp, int i, MChain<R>& ch, Trace& trace) {
+  if (i < 0) return mnee_straight_chain(sc, mats, sp, lp, ch, trace);
+  const DSphere<SR>& sph = sc.spheres[i];
+  const DMaterial<SR>& m = mats[sph.mat];
+  if (m.type != MAT_DIELECTRIC) return 0;
+  V3<R> to_sphere = V3<R>{R(sph.c[0]), R(sph.c[1]), R(sph.c[2])} - sp, to_light = lp - sp;
+  R ds = len(to_sphere), dl = len(to_light);
+  if (ds > dl + R(sph.radius)) return 0;
+  if (ds < R(sph.radius)) return 0;
+  if (dot(to_sphere * (R(1) / ds), to_light * (R(1) / dl)) < R(0)) return 0;
+  return mnee_sphere_seed_chain(sph, m, sp, lp, ch);
+}
+
 template <class R, class SR, class Trace> RTX_DEV bool mnee_connect(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<R> sp, V3<R> lp, R& throughput, Trace& trace) {
   for (int i = -1; i < sc.n_spheres; ++i) {
     MChain<R> ch{};
-    int n = 0;
-    if (i < 0) {
-      n = mnee_straight_chain(sc, mats, sp, lp, ch, trace);
-    } else {
-      const DSphere<SR>& sph = sc.spheres[i];
-      const DMaterial<SR>& m = mats[sph.mat];
-      if (m.type != MAT_DIELECTRIC) continue;
-      V3<R> to_sphere = V3<R>{R(sph.c[0]), R(sph.c[1]), R(sph.c[2])} - sp, to_light = lp - sp;
-      R ds = len(to_sphere), dl = len(to_light);
-      if (ds > dl + R(sph.radius)) continue;
-      if (ds < R(sph.radius)) continue;
-      if (dot(to_sphere * (R(1) / ds), to_light * (R(1) / dl)) < R(0)) continue;
-      n = mnee_sphere_seed_chain(sph, m, sp, lp, ch);
-    }
+    const int n = mnee_attempt_chain(sc, mats, sp, lp, i, ch, trace);
     if (n == 0) continue;
     RTX_SITE(22)
     if (mnee_solve(sc, sp, lp, ch, n, throughput, trace)) { RTX_SITE(24) return true; }
@@ -417,6 +419,35 @@ template <class SR, class Trace> RTX_DEV bool mnee_evaluate(const DScene<SR>& sc
   }
   contribution_out = v3_to<SR>(contribution);
   return any;
+}
+
+// ---- MNEE::evaluate cut at its solves, for a kernel that batches them (render_fused_mnee_batched_kernel) ----
+// The attempts of a vertex in the order mnee_evaluate makes them: light j = 0 .. lights - 1, for each the straight chain (i = -1)
+// and the seed chain through every sphere (i = 0 ..).  mnee_next_attempt moves (j, i) forward to the first attempt that has a
+// chain (false: none left); mnee_run_attempt runs the solver on that attempt and, if it converges, returns the light's
+// contribution - after which the caller goes on with (j + 1, -1), as connect_to_light returns at the first chain that converges,
+// or with (j, i + 1) otherwise.  The chain is built twice (to see that it exists, and again for the solve; `quiet` answers the
+// second build's queries without counting them), which costs a thousandth of a solve and keeps 60 registers free between the two.
+template <class SR, class Trace> RTX_DEV bool mnee_next_attempt(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<double> hp, PathKey key, int bounce, int& j, int& i, Trace& trace) {
+  const int total = mnee_light_count(sc);
+  for (; j < total; ++j, i = -1) {
+    const MneeLight<double> L = mnee_light(sc, mats, hp, key, bounce, j);
+    for (; i < sc.n_spheres; ++i) {
+      MChain<double> ch{};
+      if (mnee_attempt_chain(sc, mats, hp, L.lp, i, ch, trace) > 0) return true;
+    }
+  }
+  return false;
+}
+template <class SR, class Trace> RTX_DEV bool mnee_run_attempt(const DScene<SR>& sc, const DMaterial<SR>* mats, V3<double> hp, PathKey key, int bounce, int j, int i, V3<double>& c, Trace& trace,
+                                                            Trace& quiet) {
+  const MneeLight<double> L = mnee_light(sc, mats, hp, key, bounce, j);
+  MChain<double> ch{};
+  const int n = mnee_attempt_chain(sc, mats, hp, L.lp, i, ch, quiet);
+  double w;
+  if (n == 0 || !mnee_solve(sc, hp, L.lp, ch, n, w, trace)) return false;
+  c = mnee_light_contribution(L, hp, w);
+  return true;
 }
 
 }  // namespace rtx

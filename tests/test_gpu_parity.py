@@ -452,6 +452,50 @@ def test_mnee_f32_follows_the_double_precision_walk(name, pkg, tracer, load_scen
     assert abs(part32 - part64) <= 0.15 * abs(part64) + 1e-7   # a handful of bright connections carry the mean (measured: 5 % apart on cornell_box)
 
 
+@pytest.mark.parametrize("name", ["cornell_box", "caustics_test", "textured", "disk_room"])
+def test_mnee_f32_batched_solves_equal_solves_on_the_spot(name, pkg, load_scene, monkeypatch):
+    """Single-precision manifold NEE launches the kernel that batches the solves of a wave (a vertex notes its solve, the wave
+    solves when most lanes hold one).  Against the instance that solves at the vertex (RTX_MNEE_ON_THE_SPOT=1): the same solves,
+    so the same counters; their contributions are summed apart from the paths', so the films agree to rounding.  And the film must
+    not depend on the grid (a contribution is a function of its task alone): bit-equal with another launch geometry."""
+    abi = pkg.abi
+    sd = load_scene(name)
+    W, H, spp = 96, 64, 24
+    kw = dict(width=W, height=H, samples_per_pixel=spp, max_depth=min(sd.max_depth, 12), seed=5, use_nee=1, use_mis=1, use_mnee=1, precision=abi.PRECISION_F32,
+              pipeline=abi.PIPELINE_FUSED)
+
+    def render(env):
+        for k in ("RTX_MNEE_ON_THE_SPOT", "RTX_ITEMS_PER_LANE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pkg.renderer.HipPathTracer(0) as pt:
+            pt.upload_scene(sd)
+            pt.set_camera(sd.camera(W, H))
+            pt.set_settings(sd.settings(**kw))
+            film = pt.render().copy()
+            return film, pt.last_stats
+
+    batched, sb = render({})
+    spot, ss = render({"RTX_MNEE_ON_THE_SPOT": "1"})
+    assert (sb.samples, sb.rays_shadow, sb.segments) == (ss.samples, ss.rays_shadow, ss.segments)
+    # (the solver is compiled twice, once into each kernel, and its double-precision algebra is contracted differently: a solve in a
+    # hundred thousand takes one probe more or fewer, measured 121 of 31.6 M queries on cornell_box)
+    assert abs(int(sb.rays_closest) - int(ss.rays_closest)) <= 1e-4 * ss.rays_closest
+    assert np.isfinite(batched).all()
+    differs = np.abs(batched.astype(np.float64) - spot).max(axis=2) > 1e-4 * (1.0 + np.abs(spot).max())
+    assert differs.mean() <= 0.001
+    other_grid, so = render({"RTX_ITEMS_PER_LANE": "2"})
+    assert np.array_equal(other_grid.view(np.uint32), batched.view(np.uint32)) and so.rays_closest == sb.rays_closest
+    half = dict(kw, shard_index=1, shard_count=2)
+    with pkg.renderer.HipPathTracer(0) as pt:
+        pt.upload_scene(sd)
+        pt.set_camera(sd.camera(W, H))
+        pt.set_settings(sd.settings(**half))
+        shard = pt.render().copy()
+    assert np.array_equal(shard.view(np.uint32), batched[1::2].view(np.uint32))
+
+
 @pytest.mark.parametrize("name", ["cornell_box", "cornell_box_quad", "caustics_test", "environment_demo", "caustics_test_bdpt", "cornell_box_quad_bdpt",
                                   "cornell_box_pathphoton"])
 def test_f32_film_within_tolerance_of_reference(name, pkg, tracer, load_scene):
