@@ -160,7 +160,7 @@ typedef struct rtx_stats {
   uint32_t pipeline_used;    /* RTX_PIPELINE_FUSED or _WAVEFRONT */
   uint32_t precision_used;   /* RTX_PRECISION_* the render ran in */
   uint32_t flags;            /* RTX_STAT_*: how the call went */
-  double seconds_photon_pass;/* PathPhoton: wall time of the photon pass (trace kernel, kd-tree build on the host, uploads); ~0 when the context reuses the
+  double seconds_photon_pass;/* PathPhoton: wall time of the photon pass (trace kernel, kd-tree and box build on the device); ~0 when the context reuses the
                               * map of an earlier render (same scene upload, seed, generator, caustic_photon_count, precision); else 0.  rays_closest
                               * includes the pass's queries in both cases */
   /* queue-based pipeline only (0 otherwise): the closest-hit traversal kernel of the ray queue */

@@ -71,6 +71,12 @@ struct WideTree {
 // bounded primitive (numbered spheres, triangles, boxes), non-zero = the reference can never hit it (built in as unhittable).
 int build_wide_tree(const DScene<float>& sc, const uint8_t* d_dead, WideTree& out, std::string& err);
 
+// PathPhoton: the photon map (kd-tree in the reference's layout, photon data, run and group boxes) from the records of the photon
+// pass, on the device (photon_build.hip).  `raw`: device array of 10 planes of n values (position, -direction, power, stored flag).
+// Waits for `stream`.  n_stored = photons in the map.
+template <class R>
+int build_photon_map(const R* raw, uint32_t n, DeviceBuffer& nodes, DeviceBuffer& data, DeviceBuffer& boxes, int32_t& n_stored, hipStream_t stream, std::string& err);
+
 // What an upload derives from the description on the host alone: computed once, shared by every device that receives the scene.
 struct ScenePrep {
   HostBvh bvh;

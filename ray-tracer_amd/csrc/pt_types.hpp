@@ -141,7 +141,7 @@ struct DRenderParams {
 // Default of DRenderParams::ph_bucket: 64 groups of 64 runs of 64 photons.  Measured on the 1080p Cornell box with 50 000 photons
 // (16 spp): walking down to 64 photons 896 ms, 1024: 470, 16384: 235, no walk: 156.
 constexpr int kPhotonBucket = 64 * 64 * 64;
-constexpr unsigned long long kPhotonMaxCount = 1ull << 26;   // caustic photons per render (5 GB of double-precision staging on the host)
+constexpr unsigned long long kPhotonMaxCount = 1ull << 26;   // caustic photons per render (photon numbers and tree positions are 32-bit; 5 GB of double-precision records)
 constexpr int kPhotonMaxGather = 128;   // largest photon_gather_count whose candidate list fits the LDS of a wave; larger counts keep the list in device memory
 struct DPhotonLight { int32_t sphere; uint32_t first, count; int32_t pad; double power[3]; };   // photons [first, first + count) leave this emissive sphere
 template <class R> struct DPhotonNode { R p[3]; int32_t axis; };       // kd-tree in the reference's implicit layout: the median of a range sits at its middle

@@ -239,28 +239,10 @@ static size_t stack_words(const rtx_ctx* c, bool f64) {
 }
 
 // PathPhoton: the caustic photon pass (ref: engine/renderer.cpp:344-372, engine/photon_integrator.hpp:93-137) — plan the
-// photons per emissive sphere on the host, trace them on the GPU, build the kd-tree on the host as PhotonMap::build does
-// (ref: engine/photon_map.hpp:104-108, :222-245) and hand it to the render through P.
+// photons per emissive sphere on the host, trace them on the GPU, build the kd-tree PhotonMap::build makes
+// (ref: engine/photon_map.hpp:104-108, :222-245) and the search's boxes there too (photon_build.hip) and hand them to the
+// render through P.  The host reads back two numbers: the photons stored and the pass's query count.
 namespace {
-// The tree is built over (position, photon index) keys: std::nth_element's moves depend on the comparisons only, so the
-// arrangement is the one the reference gets on its photon records, at a third of the bytes moved.  The two sides of a split are
-// independent; the first levels build them on separate threads.
-struct PhotonKey { double p[3]; uint32_t idx; int32_t axis; };
-void photon_build_tree(PhotonKey* ph, size_t start, size_t end, int depth) {
-  if (end - start <= 1) return;
-  const int axis = depth % 3;
-  const size_t mid = start + (end - start) / 2;
-  std::nth_element(ph + start, ph + mid, ph + end, [axis](const PhotonKey& a, const PhotonKey& b) { return a.p[axis] < b.p[axis]; });
-  ph[mid].axis = axis;
-  if (depth < 4 && end - start > 8192) {
-    std::thread left(photon_build_tree, ph, start, mid, depth + 1);
-    photon_build_tree(ph, mid + 1, end, depth + 1);
-    left.join();
-  } else {
-    photon_build_tree(ph, start, mid, depth + 1);
-    photon_build_tree(ph, mid + 1, end, depth + 1);
-  }
-}
 // `reused` comes back true when the context already held the map of these inputs (nothing was traced or built).
 template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderParams& P, const DScene<R>& sc, size_t lds_bytes, hipStream_t stream, bool& reused) {
   reused = false;
@@ -306,7 +288,6 @@ template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderPar
     return RTX_OK;
   }
   key.valid = false;
-  // the host stages every photon record once (10 values each) to build the kd-tree: bounded to what a host can hold
   if (total > kPhotonMaxCount) return fail(RTX_ERR_INVALID_ARGUMENT, "caustic_photon_count %llu is too large (at most %llu)", (unsigned long long)s->caustic_photon_count, (unsigned long long)kPhotonMaxCount);
   const uint32_t n = (uint32_t)total;
   if (!c->ph_lights.upload(plan.data(), plan.size() * sizeof(DPhotonLight)) || !c->ph_targets.upload(targets.data(), targets.size() * sizeof(int32_t)) ||
@@ -315,53 +296,19 @@ template <class R> int photon_pass(rtx_ctx* c, const rtx_settings* s, DRenderPar
   launch_photon_trace(sc, P, (const DPhotonLight*)c->ph_lights.ptr, (int)plan.size(), (const int32_t*)c->ph_targets.ptr, (int)targets.size(), n, (R*)c->ph_out.ptr,
                       (DCounters*)c->counters.ptr, lds_bytes, stream);
   HIP_TRY(hipGetLastError());
-  std::vector<R> raw((size_t)n * 10);
   DCounters pass_counters;
-  HIP_TRY(hipMemcpyAsync(raw.data(), c->ph_out.ptr, raw.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipMemcpyAsync(&pass_counters, c->counters.ptr, sizeof pass_counters, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
   auto remember = [&](int32_t stored) {
     key.valid = true; key.scene_generation = c->scene_generation; key.photon_count = (unsigned long long)s->caustic_photon_count; key.seed = P.seed; key.rng = P.rng;
     key.f64 = is_f64; key.bucket = P.ph_bucket; key.n_photons = stored; key.closest = pass_counters.closest;
   };
-  std::vector<PhotonKey> ph;
-  ph.reserve(n);
-  for (uint32_t i = 0; i < n; ++i) {   // in emission order, as the reference's push_back sequence
-    if (raw[(size_t)9 * n + i] == R(0)) continue;
-    PhotonKey q;
-    for (int a = 0; a < 3; ++a) q.p[a] = (double)raw[(size_t)a * n + i];
-    q.idx = i; q.axis = 0;
-    ph.push_back(q);
-  }
-  if (ph.empty()) { remember(0); return RTX_OK; }
-  photon_build_tree(ph.data(), 0, ph.size(), 0);
-  std::vector<DPhotonNode<R>> nodes(ph.size());
-  std::vector<DPhotonData<R>> data(ph.size());
-  for (size_t i = 0; i < ph.size(); ++i) {
-    const size_t src = ph[i].idx;
-    nodes[i].axis = ph[i].axis;
-    for (int a = 0; a < 3; ++a) { nodes[i].p[a] = raw[(size_t)a * n + src]; data[i].dir[a] = raw[(size_t)(3 + a) * n + src]; data[i].power[a] = raw[(size_t)(6 + a) * n + src]; }
-  }
-  // Neighbours in the tree's array are neighbours in space: the box of every run of 64 photons lets the search skip the run,
-  // the box of every group of 64 runs (stored after the run boxes) the group.
-  const size_t n_runs = (nodes.size() + 63) / 64, n_groups = (n_runs + 63) / 64;
-  std::vector<DPhotonBox<R>> boxes(n_runs + n_groups);
-  for (size_t b = 0; b < n_runs; ++b) {
-    DPhotonBox<R>& bx = boxes[b];
-    for (int a = 0; a < 3; ++a) bx.lo[a] = bx.hi[a] = nodes[b * 64].p[a];
-    for (size_t i = b * 64; i < std::min(nodes.size(), b * 64 + 64); ++i)
-      for (int a = 0; a < 3; ++a) { bx.lo[a] = std::min(bx.lo[a], nodes[i].p[a]); bx.hi[a] = std::max(bx.hi[a], nodes[i].p[a]); }
-  }
-  for (size_t g = 0; g < n_groups; ++g) {
-    DPhotonBox<R>& bx = boxes[n_runs + g];
-    bx = boxes[g * 64];
-    for (size_t b = g * 64; b < std::min(n_runs, g * 64 + 64); ++b)
-      for (int a = 0; a < 3; ++a) { bx.lo[a] = std::min(bx.lo[a], boxes[b].lo[a]); bx.hi[a] = std::max(bx.hi[a], boxes[b].hi[a]); }
-  }
-  if (!c->ph_nodes.upload(nodes.data(), nodes.size() * sizeof(DPhotonNode<R>)) || !c->ph_data.upload(data.data(), data.size() * sizeof(DPhotonData<R>)) ||
-      !c->ph_boxes.upload(boxes.data(), boxes.size() * sizeof(DPhotonBox<R>)))
-    return fail(RTX_ERR_OUT_OF_MEMORY, "photon map (%zu photons)", ph.size());
-  P.ph_nodes = c->ph_nodes.ptr; P.ph_data = c->ph_data.ptr; P.ph_boxes = c->ph_boxes.ptr; P.n_photons = (int32_t)ph.size();
+  int32_t stored = 0;
+  std::string berr;
+  const int brc = build_photon_map((const R*)c->ph_out.ptr, n, c->ph_nodes, c->ph_data, c->ph_boxes, stored, stream, berr);   // (waits for the stream: the counters have arrived)
+  if (brc != RTX_OK) return fail(brc, "%s (%u photons)", berr.c_str(), n);
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (stored == 0) { remember(0); return RTX_OK; }
+  P.ph_nodes = c->ph_nodes.ptr; P.ph_data = c->ph_data.ptr; P.ph_boxes = c->ph_boxes.ptr; P.n_photons = stored;
   remember(P.n_photons);
   return RTX_OK;
 }
