@@ -79,6 +79,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the double-precision and id-agreement legs and the c3 / c5 lines (profiling runs)")
     ap.add_argument("--no-configs", action="store_true", help="skip the c3 / c5 lines only")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="--multi process on a machine with fewer GPUs: every rank renders on GPU 0 and the ranks meet over gloo (films staged through host memory); exercises the rank code, the timings mean nothing")
     ap.add_argument("--dry-launch", action="store_true", help="launcher rehearsal without a GPU: the ranks meet over gloo, render nothing, rank 0 prints a stub line")
     return ap.parse_args(argv)
 
@@ -99,7 +101,7 @@ def launch_ranks(args, argv):
     (a process that has touched the GPU must not be replaced, and needs not be: the child is a child)."""
     if not args.dry_launch:
         have = visible_gpus()
-        if have < args.gpus:
+        if have < (1 if args.rehearse_on_one_gpu else args.gpus):
             print(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible on this node: nothing was started", file=sys.stderr)
             return 2
     env = dict(os.environ)
@@ -153,7 +155,7 @@ class Runner:
         # Process mode: every rank's rows of every scene lie in ONE buffer (parallel.ShardedFilms), so a step gathers once.
         import importlib
         parallel = importlib.import_module("raytracer_amd.parallel")
-        self.films = parallel.ShardedFilms([(j["H"], j["W"]) for j in self.jobs], rank if shards > 1 else 0, shards, self.dev)
+        self.films = parallel.ShardedFilms([(j["H"], j["W"]) for j in self.jobs], rank if shards > 1 else 0, shards, self.dev, via_host=args.rehearse_on_one_gpu)
         for j, local in zip(self.jobs, self.films.local):
             j["local"] = local
         self.gather_events = []
@@ -208,9 +210,10 @@ def measure(runner, torch, dist, world, steps, warmup):
         films = runner.step()
     fence()
     elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=runner.dev)
+    where = "cpu" if runner.films.via_host else runner.dev   # (gloo takes host tensors only)
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=where)
     tot = torch.tensor([float(sum(s.samples for s in runner.stats)), float(sum(s.rays_closest + s.rays_shadow for s in runner.stats))], dtype=torch.float64,
-                       device=runner.dev)
+                       device=where)
     if world > 1 and not runner.single_ids:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -286,14 +289,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1")) if not single_ids else args.gpus
     rank = int(os.environ.get("RANK", "0")) if not single_ids else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if not single_ids else single_ids[0]
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} disagrees with WORLD_SIZE {world}")
     torch.cuda.set_device(local_rank)
     if world > 1 and not single_ids:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     parallelism = ("single GPU" if world == 1 else
                    f"row-interleaved x{world}, one process over all GPUs (rtx_create_multi, devices {single_ids}), film gather by {'RCCL send/recv' if args.gather == 'rccl' else 'peer copies'}" if single_ids else
-                   f"row-interleaved x{world}, one process per GPU, one film gather per step over RCCL")
+                   f"row-interleaved x{world}, one process per GPU, one film gather per step over RCCL" + (" (REHEARSAL: all ranks on GPU 0, gloo through host memory)" if args.rehearse_on_one_gpu else ""))
 
     runner = Runner(pkg, torch, dist, args, args.config, world, rank, local_rank, single_ids)
     films, elapsed, total_samples, total_rays = measure(runner, torch, dist, world, args.steps, args.warmup)

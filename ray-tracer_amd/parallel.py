@@ -48,7 +48,10 @@ class ShardedFilms:
     receives into one [world, total] buffer and re-interleaves each film with one strided copy:
     packed row j of rank k is film row k + world * j."""
 
-    def __init__(self, shapes, rank: int, world: int, device):
+    def __init__(self, shapes, rank: int, world: int, device, via_host: bool = False):
+        # via_host: the ranks meet over gloo (rehearsals on a machine with fewer GPUs than ranks): gloo takes host tensors only, so
+        # the buffer is copied to host memory with a synchronous copy, gathered there, and copied back on rank 0.
+        self.via_host = bool(via_host)
         self.shapes, self.rank, self.world = [(int(h), int(w)) for h, w in shapes], rank, world
         self.rmax = [shard_rows(h, 0, world) for h, _ in self.shapes]
         sizes = [r * w * 3 for r, (_, w) in zip(self.rmax, self.shapes)]
@@ -70,10 +73,19 @@ class ShardedFilms:
         """-> the whole films [H, W, 3] on rank 0 (views of buffers this object keeps), None on the other ranks."""
         if self.world == 1:
             return list(self.local)
-        if self.rank != 0:
+        if self.via_host:
+            send = self.send.cpu()   # synchronous: the kernels that fill the buffer have finished when it returns
+            if self.rank != 0:
+                dist.gather(send, gather_list=None, dst=0)
+                return None
+            parts = [torch.empty_like(send) for _ in range(self.world)]
+            dist.gather(send, gather_list=parts, dst=0)
+            self.recv.copy_(torch.stack(parts))
+        elif self.rank != 0:
             dist.gather(self.send, gather_list=None, dst=0)
             return None
-        dist.gather(self.send, gather_list=list(self.recv.unbind(0)), dst=0)
+        else:
+            dist.gather(self.send, gather_list=list(self.recv.unbind(0)), dst=0)
         films = []
         for (h, w), off, r, full in zip(self.shapes, self.offs, self.rmax, self.full):
             part = self.recv[:, off: off + r * w * 3].view(self.world, r, w, 3)
