@@ -12,9 +12,9 @@
 
 constexpr int kUnroll = 16;
 
-enum Op { FMA, MOV, AND, MINU, CVTUB, MAXF, ADDU, LSHL, RCP, MULF, ADDF, MIN3F, CNDMASK, MULLO, FMA64, PERM, ORSDWA, BFE, CMPF, LSHLOR, N_OPS };
+enum Op { FMA, MOV, AND, MINU, CVTUB, MAXF, ADDU, LSHL, RCP, MULF, ADDF, MIN3F, CNDMASK, MULLO, FMA64, PERM, ORSDWA, BFE, CMPF, LSHLOR, PKFMA16, PKMAX16, CNDM, N_OPS };
 static const char* kNames[N_OPS] = {"v_fma_f32", "v_mov_b32", "v_and_b32", "v_min_u32", "v_cvt_f32_ubyte1", "v_max_f32", "v_add_u32", "v_lshlrev_b32", "v_rcp_f32", "v_mul_f32",
-                                    "v_add_f32", "v_min3_f32", "v_cndmask_b32", "v_mul_lo_u32", "v_fma_f64", "v_perm_b32", "v_or_b32_sdwa(byte1)", "v_bfe_u32", "v_cmp_lt_f32", "v_lshl_or_b32"};
+                                    "v_add_f32", "v_min3_f32", "v_cndmask_b32", "v_mul_lo_u32", "v_fma_f64", "v_perm_b32", "v_or_b32_sdwa(byte1)", "v_bfe_u32", "v_cmp_lt_f32", "v_lshl_or_b32", "v_pk_fma_f16", "v_pk_max_f16", "v_cndmask_b32(sgpr mask)"};
 
 template <int OP> __device__ __forceinline__ void issue(float& a, unsigned& u, float b, float c, unsigned m, float other) {
   if (OP == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
@@ -37,6 +37,9 @@ template <int OP> __device__ __forceinline__ void issue(float& a, unsigned& u, f
   else if (OP == BFE) asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(a) : "v"(u));
   else if (OP == CMPF) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a), "v"(b) : "vcc");
   else if (OP == LSHLOR) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(u) : "v"(m));
+  else if (OP == PKFMA16) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(u) : "v"(0x3c003c00u), "v"(0x00010001u));
+  else if (OP == PKMAX16) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(u) : "v"(0x3c003c00u));
+  else if (OP == CNDM) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "s"(0x5555555555555555ull));
 }
 
 template <int A, int B> __global__ __launch_bounds__(256) void mix_kernel(float* out, int iters, float seed) {
@@ -113,6 +116,8 @@ int main() {
   run<ORSDWA, ORSDWA>(cus, d_out); run<BFE, BFE>(cus, d_out); run<CMPF, CMPF>(cus, d_out); run<LSHLOR, LSHLOR>(cus, d_out);
   run<FMA, ORSDWA>(cus, d_out); run<FMA, BFE>(cus, d_out); run<FMA, CMPF>(cus, d_out); run<FMA, LSHLOR>(cus, d_out); run<ORSDWA, MAXF>(cus, d_out); run<ORSDWA, MINU>(cus, d_out);
   run<CMPF, MAXF>(cus, d_out); run<AND, MAXF>(cus, d_out); run<ADDU, MINU>(cus, d_out); run<MULF, MAXF>(cus, d_out);
+  run<PKFMA16, PKFMA16>(cus, d_out); run<PKMAX16, PKMAX16>(cus, d_out); run<CNDM, CNDM>(cus, d_out);
+  run<PKFMA16, PKMAX16>(cus, d_out); run<PKFMA16, PERM>(cus, d_out); run<FMA, PKMAX16>(cus, d_out); run<FMA, PKFMA16>(cus, d_out); run<FMA, CNDM>(cus, d_out); run<CNDM, MAXF>(cus, d_out);
   CHECK(hipFree(d_out));
   return 0;
 }
