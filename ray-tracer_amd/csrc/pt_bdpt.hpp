@@ -133,109 +133,185 @@ template <class R> struct BdptStore {
 
 struct BdptTally { uint32_t closest, shadow, segments; };
 
+template <class R> struct BdptEps { static constexpr R v = R(1e-6); };   // BDPT_EPSILON, ref: engine/bdpt.cpp:14
+
+// Shared by both subpaths (ref: engine/bdpt.cpp:145-217 and :248-306): make the surface vertex of a hit.
+template <class R> RTX_DEV BdptVertex<R> bdpt_surface_vertex(const DScene<R>& sc, const DMaterial<R>* mats, const Hit<R>& rec, const Ray<R>& r, V3<R> thr, bool eye) {
+  const DMaterial<R>& m = mats[rec.mat];
+  BdptVertex<R> v;
+  v.type = 2; v.p = rec.p; v.n = rec.n; v.mat_type = m.type;
+  v.albedo = albedo_at(sc, m, rec);
+  v.Le = eye ? mk3(m.emission) : V3<R>{R(0), R(0), R(0)};
+  v.roughness = m.fuzz; v.ior = m.ior; v.thr = thr;
+  v.wi = -normalize(r.d);
+  v.wo = {R(0), R(0), R(0)}; v.pdf_fwd = R(0);
+  return v;
+}
+// Continuation of a subpath at v (sample, throughput, roulette).  Returns false when the path ends here; v.wo and
+// v.pdf_fwd are set only when it goes on, as in the reference (:211-213).
+template <class R> RTX_DEV bool bdpt_advance(BdptVertex<R>& v, const U4& rn, int bounce, V3<R>& thr, Ray<R>& r) {
+  const R eps = BdptEps<R>::v;
+  V3<R> wo, f;
+  R pdf;
+  if (!bdpt_sample_bsdf(v, rn, wo, pdf, f)) return false;
+  if (pdf < eps) return false;
+  const R cos_theta = abs_(dot(v.n, wo));
+  thr = thr * (f * (cos_theta / pdf));
+  if (bounce > 3) {
+    const R q = max_(R(0.05), R(1) - max_(thr.x, max_(thr.y, thr.z)));
+    if (u16lo<R>(rn.z) < q) return false;
+    thr = thr * (R(1) / (R(1) - q));
+  }
+  v.wo = wo; v.pdf_fwd = pdf;
+  r = {v.p, wo};
+  return true;
+}
+// (pdf_rev / pdf_fwd)^2 of a connection vertex, the term mis_weight adds for it (ref: engine/bdpt.cpp:671-694)
+template <class R> RTX_DEV R bdpt_mis_term(const BdptVertex<R>& v) {
+  const R eps = BdptEps<R>::v;
+  const R pr = bdpt_pdf(v.n, v.mat_type, v.roughness, v.wo, v.wi);
+  if (v.pdf_fwd > eps && pr > eps) { const R ri = pr / v.pdf_fwd; return ri * ri; }
+  return R(0);
+}
+template <class R> RTX_DEV void bdpt_keep(const BdptStore<R>& store, int& n_light, const BdptVertex<R>& v, bool origin) {
+  const int k = n_light++;
+  store.put3(0, k, v.p); store.put3(3, k, v.n); store.put3(6, k, v.thr); store.put3(9, k, v.albedo); store.put3(12, k, v.wi);
+  store.at(15, k) = v.roughness;
+  store.at(16, k) = bdpt_mis_term(v);
+  store.at(17, k) = R(v.mat_type | (origin ? 16 : 0));
+}
+
+// The origin of the light subpath (ref: engine/bdpt.cpp sample_light_origin :311-413): the light vertex, the emission direction and
+// its two pdfs.  false: the scene has no light.
+template <class R> RTX_DEV bool bdpt_light_origin(const DScene<R>& sc, const DMaterial<R>* mats, PathKey key, BdptVertex<R>& lv, V3<R>& dir, R& pdf_pos, R& pdf_dir) {
+  const U4 rn = rng_block(key.rng, key.pixel, key.seed, key.sample, 0x8001u);
+  int n_sph = 0;
+  for (int i = 0; i < sc.n_spheres; ++i) { const DMaterial<R>& m = mats[sc.spheres[i].mat]; n_sph += len2(mk3(m.emission)) > R(0.001) ? 1 : 0; }
+  const int total = sc.n_points + n_sph + sc.n_quads + sc.n_disks;
+  if (total <= 0) return false;
+  const R choice_pdf = R(1) / R(total);
+  int idx = (int)(u16hi<R>(rn.z) * R(total));
+  idx = idx < total - 1 ? idx : total - 1;
+  lv.type = 1; lv.mat_type = MAT_LAMBERTIAN; lv.albedo = {R(1), R(1), R(1)}; lv.thr = {R(1), R(1), R(1)};
+  lv.roughness = R(0); lv.ior = R(1.5); lv.wi = {R(0), R(0), R(0)}; lv.wo = {R(0), R(0), R(0)};
+  if (idx < sc.n_points) {
+    lv.p = mk3(sc.points[idx].pos); lv.n = {R(0), R(1), R(0)}; lv.Le = mk3(sc.points[idx].I);
+    pdf_pos = choice_pdf;
+    dir = unit_vector(u16hi<R>(rn.y), u16lo<R>(rn.y));
+    pdf_dir = R(1) / (R(4) * Consts<R>::pi);
+  } else if (idx < sc.n_points + n_sph) {
+    int want = idx - sc.n_points, which = 0;
+    for (int i = 0; i < sc.n_spheres; ++i) {
+      const DMaterial<R>& m = mats[sc.spheres[i].mat];
+      if (len2(mk3(m.emission)) > R(0.001)) { if (want == 0) { which = i; break; } --want; }
+    }
+    const DSphere<R>& sp = sc.spheres[which];
+    const V3<R> d = unit_vector(u16hi<R>(rn.y), u16lo<R>(rn.y));
+    lv.p = mk3(sp.c) + d * sp.radius; lv.n = d; lv.Le = mk3(mats[sp.mat].emission);
+    pdf_pos = choice_pdf / (R(4) * Consts<R>::pi * sp.radius * sp.radius);
+    dir = bdpt_cosine_hemisphere(d, u16hi<R>(rn.x), u16lo<R>(rn.x));
+    pdf_dir = dot(d, dir) * BdptConst<R>::inv_pi;
+  } else if (idx < sc.n_points + n_sph + sc.n_quads) {
+    const DQuad<R>& q = sc.quads[idx - sc.n_points - n_sph];
+    lv.p = mk3(q.corner) + (mk3(q.eu) * u16hi<R>(rn.y) + mk3(q.ev) * u16lo<R>(rn.y));   // ref: engine/primitives.hpp:258-262
+    lv.n = mk3(q.n); lv.Le = mk3(q.Le);
+    pdf_pos = choice_pdf * (R(1) / q.area);
+    dir = bdpt_cosine_hemisphere(lv.n, u16hi<R>(rn.x), u16lo<R>(rn.x));
+    pdf_dir = dot(lv.n, dir) * BdptConst<R>::inv_pi;
+  } else {
+    const DDisk<R>& dl = sc.disks[idx - sc.n_points - n_sph - sc.n_quads];
+    lv.p = disk_point(dl, u16hi<R>(rn.y), u16lo<R>(rn.y));
+    lv.n = mk3(dl.n); lv.Le = mk3(dl.Le);
+    pdf_pos = choice_pdf * (R(1) / dl.area);
+    dir = bdpt_cosine_hemisphere(lv.n, u16hi<R>(rn.x), u16lo<R>(rn.x));
+    pdf_dir = dot(lv.n, dir) * BdptConst<R>::inv_pi;
+  }
+  lv.pdf_fwd = pdf_pos;
+  return true;
+}
+
+// One strategy's contribution, weighted and clamped (ref: engine/bdpt.cpp:87-125)
+template <class R> RTX_DEV void bdpt_add_strategy(V3<R>& L, const DRenderParams& P, V3<R> Lp, R sum_ri) {
+  const R clamp_max = R(P.clamp_max);
+  V3<R> wl = Lp * (P.use_mis ? R(1) / sum_ri : R(1));
+  if (clamp_max > R(0)) {
+    const R lum = R(0.2126) * wl.x + R(0.7152) * wl.y + R(0.0722) * wl.z;
+    if (lum > clamp_max) wl = wl * (clamp_max / lum);
+  }
+  L = L + wl;
+}
+
+// The eye vertex of a round of connections: what connect_paths reads of it.
+template <class R> struct BdptEye {
+  V3<R> p, n, thr, albedo, wi;
+  R roughness, eye_term;
+  int mat_type;
+};
+template <class R> RTX_DEV BdptEye<R> bdpt_eye_of(const BdptVertex<R>& ev) {
+  return {ev.p, ev.n, ev.thr, ev.albedo, ev.wi, ev.roughness, bdpt_mis_term(ev), ev.mat_type};
+}
+// s = 0: the eye subpath found the light by itself
+template <class R> RTX_DEV void bdpt_strategy_s0(V3<R>& L, const DRenderParams& P, const BdptVertex<R>& ev, R eye_term) {
+  const bool ev_light = ev.type == 1 || len2(ev.Le) > R(0.001);
+  bdpt_add_strategy(L, P, ev_light ? ev.thr * ev.Le : V3<R>{R(0), R(0), R(0)}, R(1) + eye_term + (ev_light ? R(1) : R(0)));
+}
+// The connection of the eye vertex with kept light vertex k (ref: connect_paths, engine/bdpt.cpp:415-487).  `occluded(ray, t_max)`
+// answers visible() (:713-723).
+template <class R, class Occ> RTX_DEV void bdpt_connect_one(const BdptStore<R>& store, int k, const BdptEye<R>& ev, V3<R> Le0, V3<R>& L, const DRenderParams& P, BdptTally& tl, Occ&& occluded) {
+  const R eps = BdptEps<R>::v;
+  const V3<R> lp = store.get3(0, k);
+  const V3<R> d = lp - ev.p;
+  const R dist_sq = len2(d);
+  const R dist = sqrt_(dist_sq);
+  // The reference asks visible() first (:449) and then finds most connections empty (a vertex facing away); the
+  // product is the same with the visibility ray last, cast only for connections that carry something.
+  const int flags = (int)store.at(17, k);
+  const bool origin = (flags & 16) != 0;
+  const V3<R> wo_eye = d * (R(1) / dist), wi_light = -wo_eye;
+  const V3<R> f_eye = bdpt_eval(ev.n, ev.mat_type, ev.albedo, ev.roughness, ev.wi, wo_eye);
+  if (len2(f_eye) < eps) return;
+  const V3<R> ln = store.get3(3, k);
+  V3<R> f_light;
+  if (origin) f_light = Le0 * abs_(dot(ln, wi_light));
+  else f_light = bdpt_eval(ln, flags & 15, store.get3(9, k), store.at(15, k), store.get3(12, k), wi_light);
+  if (len2(f_light) < eps) return;
+  R G = R(0);   // geometry_term, :725-738
+  if (!(dist_sq < eps)) G = abs_(dot(ev.n, wo_eye)) * abs_(dot(ln, -wo_eye)) / dist_sq;
+  if (!(dist < eps)) {   // visible(), :713-723
+    ++tl.shadow;
+    const Ray<R> sr = {ev.p, wo_eye};
+    if (occluded(sr, dist - R(0.001))) return;
+  }
+  const R sum_ri = R(1) + ev.eye_term + store.at(16, k) + (origin ? R(0.5) : R(0));
+  const V3<R> light_c = origin ? f_light : store.get3(6, k) * f_light;
+  bdpt_add_strategy(L, P, ((ev.thr * f_eye) * light_c) * G, sum_ri);
+}
+
+// The light vertex an eye subpath ends with when it meets an area light (ref: engine/bdpt.cpp:153-166)
+template <class R> RTX_DEV BdptVertex<R> bdpt_area_light_vertex(const DScene<R>& sc, const Hit<R>& rec, const Ray<R>& r, V3<R> thr) {
+  BdptVertex<R> lv;
+  lv.type = 1; lv.p = rec.p; lv.n = rec.n; lv.mat_type = MAT_LAMBERTIAN; lv.albedo = {R(1), R(1), R(1)};
+  lv.Le = area_light_emission(sc, rec.mat); lv.thr = thr; lv.roughness = R(0); lv.ior = R(1.5);
+  lv.wi = -normalize(r.d); lv.wo = {R(0), R(0), R(0)}; lv.pdf_fwd = R(0);
+  return lv;
+}
+
 // One sample: the radiance BDPTIntegrator::Li returns for the camera ray `ray`.
 template <class R, int MODE>
 RTX_DEV V3<R> bdpt_sample(const DScene<R>& sc, const DMaterial<R>* mats, const DRenderParams& P, PathKey key, Ray<R> ray, LaneStack st, const BdptStore<R>& store,
                           BdptTally& tl) {
-  const R eps = R(1e-6);   // BDPT_EPSILON, ref: engine/bdpt.cpp:14
-  const R clamp_max = R(P.clamp_max);
+  const R eps = BdptEps<R>::v;
   int n_light = 0;         // kept (connectible) light vertices
   V3<R> Le0 = {R(0), R(0), R(0)};
 
-  // Shared by both subpaths (ref: engine/bdpt.cpp:145-217 and :248-306): make the surface vertex of a hit.
-  auto surface_vertex = [&](const Hit<R>& rec, const Ray<R>& r, V3<R> thr, bool eye) {
-    const DMaterial<R>& m = mats[rec.mat];
-    BdptVertex<R> v;
-    v.type = 2; v.p = rec.p; v.n = rec.n; v.mat_type = m.type;
-    v.albedo = albedo_at(sc, m, rec);
-    v.Le = eye ? mk3(m.emission) : V3<R>{R(0), R(0), R(0)};
-    v.roughness = m.fuzz; v.ior = m.ior; v.thr = thr;
-    v.wi = -normalize(r.d);
-    v.wo = {R(0), R(0), R(0)}; v.pdf_fwd = R(0);
-    return v;
-  };
-  // Continuation of a subpath at v (sample, throughput, roulette).  Returns false when the path ends here; v.wo and
-  // v.pdf_fwd are set only when it goes on, as in the reference (:211-213).
-  auto advance = [&](BdptVertex<R>& v, const U4& rn, int bounce, V3<R>& thr, Ray<R>& r) {
-    V3<R> wo, f;
-    R pdf;
-    if (!bdpt_sample_bsdf(v, rn, wo, pdf, f)) return false;
-    if (pdf < eps) return false;
-    const R cos_theta = abs_(dot(v.n, wo));
-    thr = thr * (f * (cos_theta / pdf));
-    if (bounce > 3) {
-      const R q = max_(R(0.05), R(1) - max_(thr.x, max_(thr.y, thr.z)));
-      if (u16lo<R>(rn.z) < q) return false;
-      thr = thr * (R(1) / (R(1) - q));
-    }
-    v.wo = wo; v.pdf_fwd = pdf;
-    r = {v.p, wo};
-    return true;
-  };
-  // (pdf_rev / pdf_fwd)^2 of a connection vertex, the term mis_weight adds for it (ref: engine/bdpt.cpp:671-694)
-  auto mis_term = [&](const BdptVertex<R>& v) {
-    const R pr = bdpt_pdf(v.n, v.mat_type, v.roughness, v.wo, v.wi);
-    if (v.pdf_fwd > eps && pr > eps) { const R ri = pr / v.pdf_fwd; return ri * ri; }
-    return R(0);
-  };
-  auto keep = [&](const BdptVertex<R>& v, bool origin) {
-    const int k = n_light++;
-    store.put3(0, k, v.p); store.put3(3, k, v.n); store.put3(6, k, v.thr); store.put3(9, k, v.albedo); store.put3(12, k, v.wi);
-    store.at(15, k) = v.roughness;
-    store.at(16, k) = mis_term(v);
-    store.at(17, k) = R(v.mat_type | (origin ? 16 : 0));
-  };
-
-  // ---- light subpath (ref: engine/bdpt.cpp:222-309, sample_light_origin :311-413) ----
+  // ---- light subpath (ref: engine/bdpt.cpp:222-309) ----
   {
-    const U4 rn = rng_block(key.rng, key.pixel, key.seed, key.sample, 0x8001u);
-    int n_sph = 0;
-    for (int i = 0; i < sc.n_spheres; ++i) { const DMaterial<R>& m = mats[sc.spheres[i].mat]; n_sph += len2(mk3(m.emission)) > R(0.001) ? 1 : 0; }
-    const int total = sc.n_points + n_sph + sc.n_quads + sc.n_disks;
-    if (total > 0) {
-      const R choice_pdf = R(1) / R(total);
-      int idx = (int)(u16hi<R>(rn.z) * R(total));
-      idx = idx < total - 1 ? idx : total - 1;
-      BdptVertex<R> lv;
-      lv.type = 1; lv.mat_type = MAT_LAMBERTIAN; lv.albedo = {R(1), R(1), R(1)}; lv.thr = {R(1), R(1), R(1)};
-      lv.roughness = R(0); lv.ior = R(1.5); lv.wi = {R(0), R(0), R(0)}; lv.wo = {R(0), R(0), R(0)};
-      V3<R> dir;
-      R pdf_pos, pdf_dir;
-      if (idx < sc.n_points) {
-        lv.p = mk3(sc.points[idx].pos); lv.n = {R(0), R(1), R(0)}; lv.Le = mk3(sc.points[idx].I);
-        pdf_pos = choice_pdf;
-        dir = unit_vector(u16hi<R>(rn.y), u16lo<R>(rn.y));
-        pdf_dir = R(1) / (R(4) * Consts<R>::pi);
-      } else if (idx < sc.n_points + n_sph) {
-        int want = idx - sc.n_points, which = 0;
-        for (int i = 0; i < sc.n_spheres; ++i) {
-          const DMaterial<R>& m = mats[sc.spheres[i].mat];
-          if (len2(mk3(m.emission)) > R(0.001)) { if (want == 0) { which = i; break; } --want; }
-        }
-        const DSphere<R>& sp = sc.spheres[which];
-        const V3<R> d = unit_vector(u16hi<R>(rn.y), u16lo<R>(rn.y));
-        lv.p = mk3(sp.c) + d * sp.radius; lv.n = d; lv.Le = mk3(mats[sp.mat].emission);
-        pdf_pos = choice_pdf / (R(4) * Consts<R>::pi * sp.radius * sp.radius);
-        dir = bdpt_cosine_hemisphere(d, u16hi<R>(rn.x), u16lo<R>(rn.x));
-        pdf_dir = dot(d, dir) * BdptConst<R>::inv_pi;
-      } else if (idx < sc.n_points + n_sph + sc.n_quads) {
-        const DQuad<R>& q = sc.quads[idx - sc.n_points - n_sph];
-        lv.p = mk3(q.corner) + (mk3(q.eu) * u16hi<R>(rn.y) + mk3(q.ev) * u16lo<R>(rn.y));   // ref: engine/primitives.hpp:258-262
-        lv.n = mk3(q.n); lv.Le = mk3(q.Le);
-        pdf_pos = choice_pdf * (R(1) / q.area);
-        dir = bdpt_cosine_hemisphere(lv.n, u16hi<R>(rn.x), u16lo<R>(rn.x));
-        pdf_dir = dot(lv.n, dir) * BdptConst<R>::inv_pi;
-      } else {
-        const DDisk<R>& dl = sc.disks[idx - sc.n_points - n_sph - sc.n_quads];
-        lv.p = disk_point(dl, u16hi<R>(rn.y), u16lo<R>(rn.y));
-        lv.n = mk3(dl.n); lv.Le = mk3(dl.Le);
-        pdf_pos = choice_pdf * (R(1) / dl.area);
-        dir = bdpt_cosine_hemisphere(lv.n, u16hi<R>(rn.x), u16lo<R>(rn.x));
-        pdf_dir = dot(lv.n, dir) * BdptConst<R>::inv_pi;
-      }
-      lv.pdf_fwd = pdf_pos;
+    BdptVertex<R> lv;
+    V3<R> dir;
+    R pdf_pos, pdf_dir;
+    if (bdpt_light_origin(sc, mats, key, lv, dir, pdf_pos, pdf_dir)) {
       Le0 = lv.Le;
-      keep(lv, true);
+      bdpt_keep(store, n_light, lv, true);
       if (!(pdf_dir < eps)) {
         V3<R> thr = lv.Le * (abs_(dot(lv.n, dir)) / (pdf_pos * pdf_dir));
         Ray<R> r = {lv.p, dir};
@@ -245,10 +321,10 @@ RTX_DEV V3<R> bdpt_sample(const DScene<R>& sc, const DMaterial<R>* mats, const D
           if (!trace_closest<R, MODE>(sc, r, R(0.001), R(1e9), rec, st)) break;
           if (rec.mat < 0) break;   // area lights end the light subpath without a vertex (:255-258)
           ++tl.segments;
-          BdptVertex<R> v = surface_vertex(rec, r, thr, false);
+          BdptVertex<R> v = bdpt_surface_vertex(sc, mats, rec, r, thr, false);
           const U4 rb = rng_block(key.rng, key.pixel, key.seed, key.sample, 0x8002u + (uint32_t)bounce);
-          const bool go = advance(v, rb, bounce, thr, r);
-          if (bdpt_connectible(v)) keep(v, false);
+          const bool go = bdpt_advance(v, rb, bounce, thr, r);
+          if (bdpt_connectible(v)) bdpt_keep(store, n_light, v, false);
           if (!go) break;
         }
       }
@@ -257,47 +333,11 @@ RTX_DEV V3<R> bdpt_sample(const DScene<R>& sc, const DMaterial<R>* mats, const D
 
   // ---- eye subpath (ref: engine/bdpt.cpp:130-220) with its connections (Li :87-125, connect_paths :415-487) ----
   V3<R> L = {R(0), R(0), R(0)};
-  auto add_strategy = [&](V3<R> Lp, R sum_ri) {
-    V3<R> wl = Lp * (P.use_mis ? R(1) / sum_ri : R(1));
-    if (clamp_max > R(0)) {
-      const R lum = R(0.2126) * wl.x + R(0.7152) * wl.y + R(0.0722) * wl.z;
-      if (lum > clamp_max) wl = wl * (clamp_max / lum);
-    }
-    L = L + wl;
-  };
-  auto connect_all = [&](const BdptVertex<R>& ev) {
-    const R eye_term = mis_term(ev);
-    const bool ev_light = ev.type == 1 || len2(ev.Le) > R(0.001);
-    // s = 0: the eye subpath found the light by itself
-    add_strategy(ev_light ? ev.thr * ev.Le : V3<R>{R(0), R(0), R(0)}, R(1) + eye_term + (ev_light ? R(1) : R(0)));
-    for (int k = 0; k < n_light; ++k) {
-      const V3<R> lp = store.get3(0, k);
-      const V3<R> d = lp - ev.p;
-      const R dist_sq = len2(d);
-      const R dist = sqrt_(dist_sq);
-      // The reference asks visible() first (:449) and then finds most connections empty (a vertex facing away); the
-      // product is the same with the visibility ray last, cast only for connections that carry something.
-      const int flags = (int)store.at(17, k);
-      const bool origin = (flags & 16) != 0;
-      const V3<R> wo_eye = d * (R(1) / dist), wi_light = -wo_eye;
-      const V3<R> f_eye = bdpt_eval(ev.n, ev.mat_type, ev.albedo, ev.roughness, ev.wi, wo_eye);
-      if (len2(f_eye) < eps) continue;
-      const V3<R> ln = store.get3(3, k);
-      V3<R> f_light;
-      if (origin) f_light = Le0 * abs_(dot(ln, wi_light));
-      else f_light = bdpt_eval(ln, flags & 15, store.get3(9, k), store.at(15, k), store.get3(12, k), wi_light);
-      if (len2(f_light) < eps) continue;
-      R G = R(0);   // geometry_term, :725-738
-      if (!(dist_sq < eps)) G = abs_(dot(ev.n, wo_eye)) * abs_(dot(ln, -wo_eye)) / dist_sq;
-      if (!(dist < eps)) {   // visible(), :713-723
-        ++tl.shadow;
-        const Ray<R> sr = {ev.p, wo_eye};
-        if (trace_occluded<R, MODE>(sc, sr, R(0.001), dist - R(0.001), st)) continue;
-      }
-      const R sum_ri = R(1) + eye_term + store.at(16, k) + (origin ? R(0.5) : R(0));
-      const V3<R> light_c = origin ? f_light : store.get3(6, k) * f_light;
-      add_strategy(((ev.thr * f_eye) * light_c) * G, sum_ri);
-    }
+  auto connect_all = [&](const BdptVertex<R>& v) {
+    const BdptEye<R> ev = bdpt_eye_of(v);
+    bdpt_strategy_s0(L, P, v, ev.eye_term);
+    for (int k = 0; k < n_light; ++k)
+      bdpt_connect_one(store, k, ev, Le0, L, P, tl, [&](const Ray<R>& sr, R t_max) { return trace_occluded<R, MODE>(sc, sr, R(0.001), t_max, st); });
   };
   {
     V3<R> thr = {R(1), R(1), R(1)};
@@ -308,16 +348,12 @@ RTX_DEV V3<R> bdpt_sample(const DScene<R>& sc, const DMaterial<R>* mats, const D
       if (!trace_closest<R, MODE>(sc, r, R(0.001), R(1e9), rec, st)) break;
       ++tl.segments;
       if (rec.mat < 0) {   // an area light ends the eye subpath with a light vertex (:153-166)
-        BdptVertex<R> lv;
-        lv.type = 1; lv.p = rec.p; lv.n = rec.n; lv.mat_type = MAT_LAMBERTIAN; lv.albedo = {R(1), R(1), R(1)};
-        lv.Le = area_light_emission(sc, rec.mat); lv.thr = thr; lv.roughness = R(0); lv.ior = R(1.5);
-        lv.wi = -normalize(r.d); lv.wo = {R(0), R(0), R(0)}; lv.pdf_fwd = R(0);
-        connect_all(lv);
+        connect_all(bdpt_area_light_vertex(sc, rec, r, thr));
         break;
       }
-      BdptVertex<R> v = surface_vertex(rec, r, thr, true);
+      BdptVertex<R> v = bdpt_surface_vertex(sc, mats, rec, r, thr, true);
       const U4 rb = rng_block(key.rng, key.pixel, key.seed, key.sample, 1u + (uint32_t)bounce);
-      const bool go = advance(v, rb, bounce, thr, r);
+      const bool go = bdpt_advance(v, rb, bounce, thr, r);
       if (bdpt_connectible(v)) connect_all(v);
       if (!go) break;
     }
@@ -367,6 +403,178 @@ __global__ __launch_bounds__(kBlock, (sizeof(R) == 4 ? RTX_BDPT_MIN_WAVES : 1)) 
   for (int k = 0; k < 4; ++k)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v[k] += (uint32_t)__shfl_xor((int)v[k], off, 64);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counters->samples, (unsigned long long)v[0]);
+    atomicAdd(&counters->closest, (unsigned long long)v[1]);
+    atomicAdd(&counters->shadow, (unsigned long long)v[2]);
+    atomicAdd(&counters->segments, (unsigned long long)v[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same integrator with the wave VOTING on what it does next (single precision).
+// render_bdpt_kernel runs one sample per lane from start to end, so a wave walks its 64 samples in lockstep: every lane waits for
+// the longest light subpath, then at every eye vertex for the lane with the most kept light vertices, and at the end for the
+// longest eye subpath: a third of the lanes were active.  Here a lane is a small state machine - START a sample (light origin),
+// EXTEND the light or the eye subpath by one vertex, or make ONE connection of its eye vertex - and every trip the wave runs the
+// one of these three that most of its lanes are waiting for; the others keep their state and wait.  A lane that finishes a
+// sample starts the next one without waiting for its neighbours.  Which lane does what when changes; what a sample computes, in
+// which order, does not (bdpt_sample's functions, strategy contributions added in the reference's order), so the film is
+// render_bdpt_kernel's.
+// ------------------------------------------------------------------------------------------
+#ifndef RTX_BDPT_VOTE_MIN_WAVES
+#define RTX_BDPT_VOTE_MIN_WAVES 3
+#endif
+template <int MODE, bool LDS_MATS>
+__global__ __launch_bounds__(kBlock, RTX_BDPT_VOTE_MIN_WAVES) void render_bdpt_voting_kernel(DScene<float> sc, DCamera<float> cam, DRenderParams P, float* __restrict__ partial,
+                                                                                             DCounters* __restrict__ counters, int stack_first_int, float* __restrict__ light_store,
+                                                                                             unsigned long long store_cap) {
+  using R = float;
+  const R eps = BdptEps<R>::v;
+  const DMaterial<R>* mats = sc.mats;
+  if constexpr (LDS_MATS) mats = stage_materials(sc);
+  const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
+  const uint32_t n_items = npix * (uint32_t)P.n_chunks;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  LaneStack st = lane_stack(stack_first_int);
+  BdptStore<R> store = {light_store + lane, (size_t)stride, (size_t)store_cap};
+  BdptTally tl = {0u, 0u, 0u};
+  uint32_t n_samples = 0;
+  enum { PH_IDLE = 0, PH_START = 1, PH_EXTEND = 2, PH_CONNECT = 3 };
+  int phase = PH_IDLE;
+  // the work item
+  uint32_t item = lane, xy = 0;
+  int s = 0, s1 = 0;
+  PathKey key = {0u, P.seed, 0u, (uint32_t)P.rng};
+  V3<R> sum = {0.f, 0.f, 0.f};
+  auto open_item = [&]() -> bool {
+    if (item >= n_items) return false;
+    const uint32_t chunk = item / npix;
+    const uint32_t pix = item - chunk * npix;
+    const uint32_t row_local = pix / (uint32_t)P.width;
+    const uint32_t x = pix - row_local * (uint32_t)P.width;
+    const uint32_t y = (uint32_t)P.shard_index + row_local * (uint32_t)P.shard_count;
+    xy = (y << 16) | x;
+    key.pixel = y * (uint32_t)P.width + x;
+    s = (int)chunk * P.chunk_spp;
+    s1 = s + P.chunk_spp < P.spp ? s + P.chunk_spp : P.spp;
+    sum = {0.f, 0.f, 0.f};
+    return true;
+  };
+  if (open_item()) phase = PH_START;
+  // the sample
+  bool eye = false;             // which subpath EXTEND extends
+  Ray<R> r = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
+  V3<R> thr = {0.f, 0.f, 0.f}, Le0 = {0.f, 0.f, 0.f}, L = {0.f, 0.f, 0.f};
+  int bounce = 0, n_light = 0, k = 0;
+  BdptEye<R> ev = {};
+  bool ev_last = false;         // the eye subpath ends with this round of connections
+  auto begin_eye = [&]() {
+    PathState<R> ps;
+    path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key);
+    r = ps.ray; thr = {1.f, 1.f, 1.f}; bounce = 0; eye = true;
+  };
+  for (;;) {
+    const int n_start = __popcll(__ballot(phase == PH_START)), n_extend = __popcll(__ballot(phase == PH_EXTEND)), n_connect = __popcll(__ballot(phase == PH_CONNECT));
+    if (n_start + n_extend + n_connect == 0) break;
+    // (a lane that starts a sample goes on to its first vertex in the same trip: starting is a prologue of extending, so that a
+    // handful of lanes between samples never wait for a majority of their own)
+    const int run = n_connect > n_extend + n_start ? PH_CONNECT : PH_EXTEND;
+    if (run == PH_EXTEND) {
+      if (phase == PH_START) {
+        if (s == s1) {
+          R* o = partial + (size_t)item * 3u;
+          o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+          item += stride;
+          if (!open_item()) phase = PH_IDLE;
+        }
+        if (phase == PH_START) {
+          key.sample = (uint32_t)s++;
+          ++n_samples;
+          n_light = 0; L = {0.f, 0.f, 0.f}; Le0 = {0.f, 0.f, 0.f};
+          bool light_path = false;   // ---- light subpath (ref: engine/bdpt.cpp:222-309) ----
+          BdptVertex<R> lv;
+          V3<R> dir;
+          R pdf_pos, pdf_dir;
+          if (bdpt_light_origin(sc, mats, key, lv, dir, pdf_pos, pdf_dir)) {
+            Le0 = lv.Le;
+            bdpt_keep(store, n_light, lv, true);
+            if (!(pdf_dir < eps)) {
+              thr = lv.Le * (abs_(dot(lv.n, dir)) / (pdf_pos * pdf_dir));
+              r = {lv.p, dir};
+              bounce = 0; eye = false;
+              light_path = true;
+            }
+          }
+          if (!light_path) begin_eye();
+          phase = PH_EXTEND;
+        }
+      }
+      if (phase == PH_EXTEND) {
+        bool end_subpath = bounce >= P.max_depth, to_connect = false;
+        if (!end_subpath) {
+          Hit<R> rec;
+          ++tl.closest;
+          const bool hit = trace_closest<R, MODE>(sc, r, 0.001f, 1e9f, rec, st);
+          if (!eye) {
+            if (!hit || rec.mat < 0) end_subpath = true;   // area lights end the light subpath without a vertex (:255-258)
+            else {
+              ++tl.segments;
+              BdptVertex<R> v = bdpt_surface_vertex(sc, mats, rec, r, thr, false);
+              const U4 rb = rng_block(key.rng, key.pixel, key.seed, key.sample, 0x8002u + (uint32_t)bounce);
+              const bool go = bdpt_advance(v, rb, bounce, thr, r);
+              if (bdpt_connectible(v)) bdpt_keep(store, n_light, v, false);
+              if (go) ++bounce; else end_subpath = true;
+            }
+          } else {   // ---- eye subpath (ref: engine/bdpt.cpp:130-220) ----
+            if (!hit) end_subpath = true;
+            else {
+              ++tl.segments;
+              BdptVertex<R> v;
+              bool go = false, connect;
+              if (rec.mat < 0) { v = bdpt_area_light_vertex(sc, rec, r, thr); connect = true; }   // an area light ends the eye subpath with a light vertex (:153-166)
+              else {
+                v = bdpt_surface_vertex(sc, mats, rec, r, thr, true);
+                const U4 rb = rng_block(key.rng, key.pixel, key.seed, key.sample, 1u + (uint32_t)bounce);
+                go = bdpt_advance(v, rb, bounce, thr, r);
+                connect = bdpt_connectible(v);
+              }
+              if (connect) {   // connect_all: the strategy s = 0 now, the kept light vertices one per CONNECT trip
+                ev = bdpt_eye_of(v);
+                bdpt_strategy_s0(L, P, v, ev.eye_term);
+                ev_last = !go; k = 0;
+                to_connect = true;
+              } else if (go) ++bounce;
+              else end_subpath = true;
+            }
+          }
+        }
+        if (to_connect) {
+          if (n_light > 0) phase = PH_CONNECT;
+          else if (ev_last) end_subpath = true;
+          else ++bounce;
+        }
+        if (end_subpath) {
+          if (!eye) begin_eye();                       // the light subpath is complete: the eye subpath starts
+          else { sum = sum + L; phase = PH_START; }    // the sample is complete
+        }
+      }
+    } else {
+      if (phase == PH_CONNECT) {
+        bdpt_connect_one(store, k, ev, Le0, L, P, tl, [&](const Ray<R>& sr, R t_max) { return trace_occluded<R, MODE>(sc, sr, 0.001f, t_max, st); });
+        if (++k == n_light) {
+          if (ev_last) { sum = sum + L; phase = PH_START; }
+          else { ++bounce; phase = PH_EXTEND; }
+        }
+      }
+    }
+  }
+  uint32_t v[4] = {n_samples, tl.closest, tl.shadow, tl.segments};
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[q] += (uint32_t)__shfl_xor((int)v[q], off, 64);
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&counters->samples, (unsigned long long)v[0]);
     atomicAdd(&counters->closest, (unsigned long long)v[1]);
