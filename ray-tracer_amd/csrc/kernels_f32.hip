@@ -35,13 +35,6 @@ void launch_photon_trace(const DScene<float>& sc, const DRenderParams& P, const 
 int launch_render_bdpt(const DScene<float>& sc, const DCamera<float>& cam, const DRenderParams& P, float* partial, DCounters* counters, const FusedLaunch& L,
                        float* light_store, unsigned long long store_cap, hipStream_t stream) {
   dim3 g(L.grid), b(kBlock);
-  if (L.bdpt_voting) {   // the wave votes on what it does next (pt_bdpt.hpp)
-    if (L.mode == MODE_FLAT && L.lds_mats) { hipLaunchKernelGGL((render_bdpt_voting_kernel<MODE_FLAT, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int, light_store, store_cap); return 0; }
-    if (L.mode == MODE_FLAT) return -1;
-    if (L.lds_mats) hipLaunchKernelGGL((render_bdpt_voting_kernel<MODE_TREE_UV, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int, light_store, store_cap);
-    else hipLaunchKernelGGL((render_bdpt_voting_kernel<MODE_TREE_UV, false>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int, light_store, store_cap);
-    return 0;
-  }
   if (L.mode == MODE_FLAT && L.lds_mats) { hipLaunchKernelGGL((render_bdpt_kernel<float, MODE_FLAT, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int, light_store, store_cap); return 0; }
   if (L.mode == MODE_FLAT) return -1;
   if (L.lds_mats) hipLaunchKernelGGL((render_bdpt_kernel<float, MODE_TREE_UV, true>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int, light_store, store_cap);

@@ -411,176 +411,4 @@ __global__ __launch_bounds__(kBlock, (sizeof(R) == 4 ? RTX_BDPT_MIN_WAVES : 1)) 
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// The same integrator with the wave VOTING on what it does next (single precision).
-// render_bdpt_kernel runs one sample per lane from start to end, so a wave walks its 64 samples in lockstep: every lane waits for
-// the longest light subpath, then at every eye vertex for the lane with the most kept light vertices, and at the end for the
-// longest eye subpath: a third of the lanes were active.  Here a lane is a small state machine - START a sample (light origin),
-// EXTEND the light or the eye subpath by one vertex, or make ONE connection of its eye vertex - and every trip the wave runs the
-// one of these three that most of its lanes are waiting for; the others keep their state and wait.  A lane that finishes a
-// sample starts the next one without waiting for its neighbours.  Which lane does what when changes; what a sample computes, in
-// which order, does not (bdpt_sample's functions, strategy contributions added in the reference's order), so the film is
-// render_bdpt_kernel's.
-// ------------------------------------------------------------------------------------------
-#ifndef RTX_BDPT_VOTE_MIN_WAVES
-#define RTX_BDPT_VOTE_MIN_WAVES 3
-#endif
-template <int MODE, bool LDS_MATS>
-__global__ __launch_bounds__(kBlock, RTX_BDPT_VOTE_MIN_WAVES) void render_bdpt_voting_kernel(DScene<float> sc, DCamera<float> cam, DRenderParams P, float* __restrict__ partial,
-                                                                                             DCounters* __restrict__ counters, int stack_first_int, float* __restrict__ light_store,
-                                                                                             unsigned long long store_cap) {
-  using R = float;
-  const R eps = BdptEps<R>::v;
-  const DMaterial<R>* mats = sc.mats;
-  if constexpr (LDS_MATS) mats = stage_materials(sc);
-  const uint32_t npix = (uint32_t)P.rows * (uint32_t)P.width;
-  const uint32_t n_items = npix * (uint32_t)P.n_chunks;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-  LaneStack st = lane_stack(stack_first_int);
-  BdptStore<R> store = {light_store + lane, (size_t)stride, (size_t)store_cap};
-  BdptTally tl = {0u, 0u, 0u};
-  uint32_t n_samples = 0;
-  enum { PH_IDLE = 0, PH_START = 1, PH_EXTEND = 2, PH_CONNECT = 3 };
-  int phase = PH_IDLE;
-  // the work item
-  uint32_t item = lane, xy = 0;
-  int s = 0, s1 = 0;
-  PathKey key = {0u, P.seed, 0u, (uint32_t)P.rng};
-  V3<R> sum = {0.f, 0.f, 0.f};
-  auto open_item = [&]() -> bool {
-    if (item >= n_items) return false;
-    const uint32_t chunk = item / npix;
-    const uint32_t pix = item - chunk * npix;
-    const uint32_t row_local = pix / (uint32_t)P.width;
-    const uint32_t x = pix - row_local * (uint32_t)P.width;
-    const uint32_t y = (uint32_t)P.shard_index + row_local * (uint32_t)P.shard_count;
-    xy = (y << 16) | x;
-    key.pixel = y * (uint32_t)P.width + x;
-    s = (int)chunk * P.chunk_spp;
-    s1 = s + P.chunk_spp < P.spp ? s + P.chunk_spp : P.spp;
-    sum = {0.f, 0.f, 0.f};
-    return true;
-  };
-  if (open_item()) phase = PH_START;
-  // the sample
-  bool eye = false;             // which subpath EXTEND extends
-  Ray<R> r = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
-  V3<R> thr = {0.f, 0.f, 0.f}, Le0 = {0.f, 0.f, 0.f}, L = {0.f, 0.f, 0.f};
-  int bounce = 0, n_light = 0, k = 0;
-  BdptEye<R> ev = {};
-  bool ev_last = false;         // the eye subpath ends with this round of connections
-  auto begin_eye = [&]() {
-    PathState<R> ps;
-    path_begin(ps, cam, P, (int)(xy & 0xffffu), (int)(xy >> 16), key);
-    r = ps.ray; thr = {1.f, 1.f, 1.f}; bounce = 0; eye = true;
-  };
-  for (;;) {
-    const int n_start = __popcll(__ballot(phase == PH_START)), n_extend = __popcll(__ballot(phase == PH_EXTEND)), n_connect = __popcll(__ballot(phase == PH_CONNECT));
-    if (n_start + n_extend + n_connect == 0) break;
-    // (a lane that starts a sample goes on to its first vertex in the same trip: starting is a prologue of extending, so that a
-    // handful of lanes between samples never wait for a majority of their own)
-    const int run = n_connect > n_extend + n_start ? PH_CONNECT : PH_EXTEND;
-    if (run == PH_EXTEND) {
-      if (phase == PH_START) {
-        if (s == s1) {
-          R* o = partial + (size_t)item * 3u;
-          o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
-          item += stride;
-          if (!open_item()) phase = PH_IDLE;
-        }
-        if (phase == PH_START) {
-          key.sample = (uint32_t)s++;
-          ++n_samples;
-          n_light = 0; L = {0.f, 0.f, 0.f}; Le0 = {0.f, 0.f, 0.f};
-          bool light_path = false;   // ---- light subpath (ref: engine/bdpt.cpp:222-309) ----
-          BdptVertex<R> lv;
-          V3<R> dir;
-          R pdf_pos, pdf_dir;
-          if (bdpt_light_origin(sc, mats, key, lv, dir, pdf_pos, pdf_dir)) {
-            Le0 = lv.Le;
-            bdpt_keep(store, n_light, lv, true);
-            if (!(pdf_dir < eps)) {
-              thr = lv.Le * (abs_(dot(lv.n, dir)) / (pdf_pos * pdf_dir));
-              r = {lv.p, dir};
-              bounce = 0; eye = false;
-              light_path = true;
-            }
-          }
-          if (!light_path) begin_eye();
-          phase = PH_EXTEND;
-        }
-      }
-      if (phase == PH_EXTEND) {
-        bool end_subpath = bounce >= P.max_depth, to_connect = false;
-        if (!end_subpath) {
-          Hit<R> rec;
-          ++tl.closest;
-          const bool hit = trace_closest<R, MODE>(sc, r, 0.001f, 1e9f, rec, st);
-          if (!eye) {
-            if (!hit || rec.mat < 0) end_subpath = true;   // area lights end the light subpath without a vertex (:255-258)
-            else {
-              ++tl.segments;
-              BdptVertex<R> v = bdpt_surface_vertex(sc, mats, rec, r, thr, false);
-              const U4 rb = rng_block(key.rng, key.pixel, key.seed, key.sample, 0x8002u + (uint32_t)bounce);
-              const bool go = bdpt_advance(v, rb, bounce, thr, r);
-              if (bdpt_connectible(v)) bdpt_keep(store, n_light, v, false);
-              if (go) ++bounce; else end_subpath = true;
-            }
-          } else {   // ---- eye subpath (ref: engine/bdpt.cpp:130-220) ----
-            if (!hit) end_subpath = true;
-            else {
-              ++tl.segments;
-              BdptVertex<R> v;
-              bool go = false, connect;
-              if (rec.mat < 0) { v = bdpt_area_light_vertex(sc, rec, r, thr); connect = true; }   // an area light ends the eye subpath with a light vertex (:153-166)
-              else {
-                v = bdpt_surface_vertex(sc, mats, rec, r, thr, true);
-                const U4 rb = rng_block(key.rng, key.pixel, key.seed, key.sample, 1u + (uint32_t)bounce);
-                go = bdpt_advance(v, rb, bounce, thr, r);
-                connect = bdpt_connectible(v);
-              }
-              if (connect) {   // connect_all: the strategy s = 0 now, the kept light vertices one per CONNECT trip
-                ev = bdpt_eye_of(v);
-                bdpt_strategy_s0(L, P, v, ev.eye_term);
-                ev_last = !go; k = 0;
-                to_connect = true;
-              } else if (go) ++bounce;
-              else end_subpath = true;
-            }
-          }
-        }
-        if (to_connect) {
-          if (n_light > 0) phase = PH_CONNECT;
-          else if (ev_last) end_subpath = true;
-          else ++bounce;
-        }
-        if (end_subpath) {
-          if (!eye) begin_eye();                       // the light subpath is complete: the eye subpath starts
-          else { sum = sum + L; phase = PH_START; }    // the sample is complete
-        }
-      }
-    } else {
-      if (phase == PH_CONNECT) {
-        bdpt_connect_one(store, k, ev, Le0, L, P, tl, [&](const Ray<R>& sr, R t_max) { return trace_occluded<R, MODE>(sc, sr, 0.001f, t_max, st); });
-        if (++k == n_light) {
-          if (ev_last) { sum = sum + L; phase = PH_START; }
-          else { ++bounce; phase = PH_EXTEND; }
-        }
-      }
-    }
-  }
-  uint32_t v[4] = {n_samples, tl.closest, tl.shadow, tl.segments};
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[q] += (uint32_t)__shfl_xor((int)v[q], off, 64);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&counters->samples, (unsigned long long)v[0]);
-    atomicAdd(&counters->closest, (unsigned long long)v[1]);
-    atomicAdd(&counters->shadow, (unsigned long long)v[2]);
-    atomicAdd(&counters->segments, (unsigned long long)v[3]);
-  }
-}
-
 }  // namespace rtx

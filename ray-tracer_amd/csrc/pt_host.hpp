@@ -159,7 +159,6 @@ struct FusedLaunch {
   int stack_first_int;  // offset (in ints) of the traversal stacks inside the dynamic LDS
   int integ = INTEG_PATH;  // INTEG_*: path tracing, path tracing with MNEE (double precision only), Whitted (TREE_UV instances only)
   bool mnee_batched = true;   // single-precision manifold NEE: the solves of a wave batched (render_fused_mnee_batched_kernel); RTX_MNEE_ON_THE_SPOT=1 in the environment launches the instance that solves at the vertex
-  bool bdpt_voting = false;   // experiment (RTX_BDPT_VOTING=1): single-precision BDPT in which the wave votes on its next step (render_bdpt_voting_kernel)
   int regroup = 0;         // experiment (RTX_FUSED_REGROUP): > 0 launches the material-coherent variant of the lean flat path tracer; lanes trade places when a wave has at least this many lanes outside its majority class
 };
 // PathPhoton photon pass (pt_photon.hpp): `out` = 10 planes of n_photons values (position, -direction, power, valid)

@@ -794,7 +794,6 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     if (mnee && !f64 && L.mode == MODE_TREE) L.mode = MODE_TREE_UV;   // the single-precision MNEE instances: flat or general
     L.integ = whitted ? INTEG_WHITTED : bdpt ? INTEG_BDPT : photon ? INTEG_PATHPHOTON : mnee ? INTEG_PATH_MNEE : INTEG_PATH;
     if (const char* e = std::getenv("RTX_MNEE_ON_THE_SPOT")) L.mnee_batched = std::atoi(e) == 0;
-    if (const char* e = std::getenv("RTX_BDPT_VOTING")) L.bdpt_voting = std::atoi(e) != 0;
     if (const char* e = std::getenv("RTX_FUSED_REGROUP")) { const int v = std::atoi(e); if (v > 0 && v <= 64) L.regroup = v; }   // experiment, see render_fused_regroup_kernel
     const size_t mat_bytes = (size_t)c->scene.dev_f.n_mats * (f64 ? sizeof(DMaterial<double>) : sizeof(DMaterial<float>));
     L.lds_mats = mat_bytes <= kMaxLdsMaterialBytes;
