@@ -17,8 +17,11 @@ PATHPHOTON_F32_BAD_PIXELS_MAX = 0.015
 # Single-precision production walk against the double-precision reference order on the fixture ray sets (pixel centres +
 # random rays with zero components, axis-parallel and short directions): share of rays whose winning primitive differs.
 # Measured per scene on MI355X: profiles/r02_parity_rates.jsonl.
-# The walk is deterministic, so the bound is the measured count of such rays itself (grazing hits on silhouettes and edges).
-F32_ID_MISMATCH_RAYS = {"normal_mapped": 3, "kitchen_sink": 1, "soup": 1}   # of 4296 (soup: 10096) rays; every other scene: 0
+# The walk is deterministic; measured counts of such rays (grazing hits on silhouettes and edges): normal_mapped 3, kitchen_sink 1,
+# soup 1, every other scene 0, of 4296 (soup: 10096) rays.  The bound leaves room for the two or three grazing rays another
+# compiler version may round the other way (5 rays = 0.12 % of a set; a walk that skips a node or a primitive differs in hundreds);
+# the measured count itself is recorded with every run (record_rate), so a drift shows.
+F32_ID_MISMATCH_RAYS_MAX = 5
 # Per-channel mean of the converged film against the reference's, relative: 1 %.
 CHANNEL_MEAN_TOL = 0.01
 PHOTON_CHANNEL_MEAN_TOL = 0.05   # PathPhoton: the mean of eight films with eight photon maps against the reference film with its ONE map (measured: 0.7 / 2.6 / 3.7 %; one map against one map: 0.7 / 3.4 / 4.7 %)
@@ -77,7 +80,7 @@ def test_closest_hit_triangle_soup_bit_exact_vs_reference(pkg, tracer, load_scen
     f32 = pt.trace_closest(fx["rays"], pkg.abi.PRECISION_F32)
     agree = (f32["hit"] == fx["hits"]["hit"]) & (f32["prim_type"] == fx["hits"]["prim_type"]) & (f32["prim_index"] == fx["hits"]["prim_index"])
     record_rate("f32_id_mismatch_soup", rate=1.0 - float(agree.mean()), mismatching=int((~agree).sum()), rays=int(len(agree)))
-    assert int((~agree).sum()) <= F32_ID_MISMATCH_RAYS["soup"], int((~agree).sum())
+    assert int((~agree).sum()) <= F32_ID_MISMATCH_RAYS_MAX, int((~agree).sum())
     hit = agree & (f32["hit"] == 1)
     assert np.abs(f32["t"][hit] - fx["hits"]["t"][hit]).max() < 1e-3 * (1 + np.abs(fx["hits"]["t"][hit]).max())
 
@@ -91,7 +94,7 @@ def test_fast_path_closest_hit_agreement(name, pkg, tracer, load_scene):
     f32 = pt.trace_closest(fx["rays"], pkg.abi.PRECISION_F32)
     agree = (f32["hit"] == fx["hits"]["hit"]) & (f32["prim_type"] == fx["hits"]["prim_type"]) & (f32["prim_index"] == fx["hits"]["prim_index"])
     record_rate("f32_id_mismatch_" + name, rate=1.0 - float(agree.mean()), mismatching=int((~agree).sum()), rays=int(len(agree)))
-    assert int((~agree).sum()) <= F32_ID_MISMATCH_RAYS.get(name, 0), int((~agree).sum())
+    assert int((~agree).sum()) <= F32_ID_MISMATCH_RAYS_MAX, int((~agree).sum())
 
 
 @pytest.mark.parametrize("case", ["kitchen_sink", "soup", "stress_300k_with_duplicates", "stress_1500k"])
