@@ -28,6 +28,14 @@ template <class R> struct MChain {
   RTX_DEV V3<R> p(int i) const { return i == 0 ? v0.p : i == 1 ? v1.p : i == 2 ? v2.p : v3.p; }
   RTX_DEV void set(int i, const MVertex<R>& v) { if (i == 0) v0 = v; else if (i == 1) v1 = v; else if (i == 2) v2 = v; else v3 = v; }
 };
+// The same for chains of at most two vertices (every seed chain through a sphere, and the straight chain through one sphere):
+// half the registers while the solver runs.
+template <class R> struct MChain2 {
+  MVertex<R> v0, v1;
+  RTX_DEV MVertex<R> get(int i) const { return i == 0 ? v0 : v1; }
+  RTX_DEV V3<R> p(int i) const { return i == 0 ? v0.p : v1.p; }
+  RTX_DEV void set(int i, const MVertex<R>& v) { if (i == 0) v0 = v; else v1 = v; }
+};
 
 template <class A, class B> struct mnee_same { static constexpr bool value = false; };
 template <class A> struct mnee_same<A, A> { static constexpr bool value = true; };
@@ -124,7 +132,7 @@ template <class S, class R, class Trace> RTX_DEV bool mnee_reproject(const DScen
 }
 
 // ref: build_path, mnee.hpp:538-617 — throughput of the chain, then a visibility walk along it
-template <class R, class SR, class Trace> RTX_DEV bool mnee_build_path(const DScene<SR>& sc, V3<R> sp, V3<R> lp, const MChain<R>& ch, int n, R& throughput, Trace& trace) {
+template <class R, class SR, class Trace, class Chain> RTX_DEV bool mnee_build_path(const DScene<SR>& sc, V3<R> sp, V3<R> lp, const Chain& ch, int n, R& throughput, Trace& trace) {
   throughput = R(1);
   for (int i = 0; i < n; ++i) {
     const MVertex<R> vi = ch.get(i);
@@ -165,7 +173,7 @@ template <class R, class SR, class Trace> RTX_DEV bool mnee_build_path(const DSc
 
 // ref: solve_manifold, mnee.hpp:442-533 — Gauss-Seidel Newton on the per-vertex refraction
 // constraints with finite-difference 2x2 Jacobians (compute_jacobian_block :354-382, solve_2x2 :387-396)
-template <class R, class SR, class Trace> RTX_DEV bool mnee_solve(const DScene<SR>& sc, V3<R> sp, V3<R> lp, MChain<R>& ch, int n, R& throughput, Trace& trace) {
+template <class R, class SR, class Trace, class Chain> RTX_DEV bool mnee_solve(const DScene<SR>& sc, V3<R> sp, V3<R> lp, Chain& ch, int n, R& throughput, Trace& trace) {
   // (the reference keeps every vertex's tangent frame in an array and renews it after the vertex's re-projection; a frame is a
   // function of the vertex's normal alone, so it is computed where it is used: the same values, a dozen registers fewer per vertex)
   constexpr bool kFast = !mnee_same<R, SR>::value;
@@ -306,7 +314,14 @@ template <class R, class SR, class Trace> RTX_DEV bool mnee_connect(const DScene
     const int n = mnee_attempt_chain(sc, mats, sp, lp, i, ch, trace);
     if (n == 0) continue;
     RTX_SITE(22)
-    if (mnee_solve(sc, sp, lp, ch, n, throughput, trace)) { RTX_SITE(24) return true; }
+    bool ok;
+    if (n <= 2) {   // the common case, with half the chain's registers
+      MChain2<R> c2 = {ch.v0, ch.v1};
+      ok = mnee_solve(sc, sp, lp, c2, n, throughput, trace);
+    } else {
+      ok = mnee_solve(sc, sp, lp, ch, n, throughput, trace);
+    }
+    if (ok) { RTX_SITE(24) return true; }
   }
   return false;
 }
@@ -445,7 +460,15 @@ template <class SR, class Trace> RTX_DEV bool mnee_run_attempt(const DScene<SR>&
   MChain<double> ch{};
   const int n = mnee_attempt_chain(sc, mats, hp, L.lp, i, ch, quiet);
   double w;
-  if (n == 0 || !mnee_solve(sc, hp, L.lp, ch, n, w, trace)) return false;
+  if (n == 0) return false;
+  bool ok;
+  if (n <= 2) {   // the common case, with half the chain's registers (a wave runs the long form only for the lanes that need it)
+    MChain2<double> c2 = {ch.v0, ch.v1};
+    ok = mnee_solve(sc, hp, L.lp, c2, n, w, trace);
+  } else {
+    ok = mnee_solve(sc, hp, L.lp, ch, n, w, trace);
+  }
+  if (!ok) return false;
   c = mnee_light_contribution(L, hp, w);
   return true;
 }
