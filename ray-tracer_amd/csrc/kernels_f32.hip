@@ -63,11 +63,11 @@ static int launch_render_fused_instance(const DScene<float>& sc, const DCamera<f
   }
   if (L.integ == INTEG_PATH_MNEE && L.mnee_batched) {   // manifold NEE with the solves of a wave batched (pt_kernels.hpp)
     if (L.mode == MODE_FLAT && L.lds_mats && !sc.env.valid && sc.n_points == 0 && sc.n_disks == 0 && sc.n_quads == 0 && P.use_nee && P.use_mis && P.rng == 1 /* RNG_PCG4D */)
-      hipLaunchKernelGGL((render_fused_mnee_batched_kernel<MODE_FLAT, true, 31>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
-    else if (L.mode == MODE_FLAT && L.lds_mats) hipLaunchKernelGGL((render_fused_mnee_batched_kernel<MODE_FLAT, true, 0>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+      hipLaunchKernelGGL((render_fused_mnee_batched_kernel<float, MODE_FLAT, true, 31>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else if (L.mode == MODE_FLAT && L.lds_mats) hipLaunchKernelGGL((render_fused_mnee_batched_kernel<float, MODE_FLAT, true, 0>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     else if (L.mode == MODE_FLAT) return -1;
-    else if (L.lds_mats) hipLaunchKernelGGL((render_fused_mnee_batched_kernel<MODE_TREE_UV, true, 0>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
-    else hipLaunchKernelGGL((render_fused_mnee_batched_kernel<MODE_TREE_UV, false, 0>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else if (L.lds_mats) hipLaunchKernelGGL((render_fused_mnee_batched_kernel<float, MODE_TREE_UV, true, 0>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else hipLaunchKernelGGL((render_fused_mnee_batched_kernel<float, MODE_TREE_UV, false, 0>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
     return 0;
   }
   if (L.integ == INTEG_PATH_MNEE) {   // manifold NEE: single-precision traces, the manifold walk itself in double (pt_mnee.hpp)

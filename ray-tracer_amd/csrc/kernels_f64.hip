@@ -80,6 +80,17 @@ int launch_render_bdpt(const DScene<double>& sc, const DCamera<double>& cam, con
 int launch_render_fused(const DScene<double>& sc, const DCamera<double>& cam, const DRenderParams& P, double* partial, DCounters* counters,
                         const FusedLaunch& L, hipStream_t stream) {
   dim3 g(L.grid), b(kBlock);
+  if (L.integ == INTEG_PATH_MNEE && L.mnee_batched) {   // the solves of a wave batched (pt_kernels.hpp)
+    if (L.mode == MODE_TREE && L.lds_mats)
+      hipLaunchKernelGGL((render_fused_mnee_batched_kernel<double, MODE_TREE, true, 0>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else if (L.mode == MODE_TREE_UV && L.lds_mats)
+      hipLaunchKernelGGL((render_fused_mnee_batched_kernel<double, MODE_TREE_UV, true, 0>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else if (!L.lds_mats && L.mode != MODE_FLAT)
+      hipLaunchKernelGGL((render_fused_mnee_batched_kernel<double, MODE_TREE_UV, false, 0>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);
+    else
+      return -1;
+    return 0;
+  }
   if (L.integ == INTEG_PATH_MNEE) {
     if (L.mode == MODE_TREE && L.lds_mats)
       hipLaunchKernelGGL((render_fused_kernel<double, MODE_TREE, true, INTEG_PATH_MNEE>), g, b, L.lds_bytes, stream, sc, cam, P, partial, counters, L.stack_first_int);

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4
 }
 
 // ------------------------------------------------------------------------------------------
-// Manifold NEE in single precision with the solves of a wave BATCHED (INTEG_PATH_MNEE, R = float).
+// Manifold NEE with the solves of a wave BATCHED (INTEG_PATH_MNEE; both precisions).
 // A manifold solve costs a hundred path vertices (20 Newton iterations of double-precision algebra and two closest-hit queries
 // per chain vertex), and only about half of the Lambertian vertices ask for one (the seed chain through a glass sphere is tried
 // when the sphere lies towards the light): solved on the spot, as render_fused_kernel does, a solve runs with 30 of a wave's 64
@@ -245,10 +245,9 @@ __global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4
 #define RTX_MNEE_BATCHED_MIN_WAVES 3   // (the same frame: 3: 197.6 ms, 4: 205.4, 5: 282.5)
 #endif
 constexpr int kMneeBatch = RTX_MNEE_BATCH;
-template <int MODE, bool LDS_MATS, int LEAN>
-__global__ __launch_bounds__(kBlock, RTX_MNEE_BATCHED_MIN_WAVES) void render_fused_mnee_batched_kernel(DScene<float> sc, DCamera<float> cam, DRenderParams P, float* __restrict__ partial,
-                                                                                                   DCounters* __restrict__ counters, int stack_first_int) {
-  using R = float;
+template <class R, int MODE, bool LDS_MATS, int LEAN>
+__global__ __launch_bounds__(kBlock, (sizeof(R) == 4 ? RTX_MNEE_BATCHED_MIN_WAVES : RTX_MNEE_MIN_WAVES)) void render_fused_mnee_batched_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
+                                                                                                                                    DCounters* __restrict__ counters, int stack_first_int) {
   if constexpr ((LEAN & 1) != 0) { sc.env.valid = 0; sc.env.importance = 0; }
   if constexpr ((LEAN & 2) != 0) { sc.n_points = 0; sc.n_disks = 0; }
   if constexpr ((LEAN & 4) != 0) { sc.n_quads = 0; }
@@ -263,15 +262,15 @@ __global__ __launch_bounds__(kBlock, RTX_MNEE_BATCHED_MIN_WAVES) void render_fus
   LaneStack st = lane_stack(stack_first_int);
   uint32_t w_steps = 0, w_shadow = 0, w_shaded = 0, w_samples = 0, extra_traces = 0;
   PathState<R> ps;
-  ps.ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}}; ps.thr = {0.f, 0.f, 0.f}; ps.acc = {0.f, 0.f, 0.f}; ps.bsdf_pdf = 0.f;
+  ps.ray = {{R(0), R(0), R(0)}, {R(0), R(0), R(1)}}; ps.thr = {R(0), R(0), R(0)}; ps.acc = {R(0), R(0), R(0)}; ps.bsdf_pdf = R(0);
   ps.bounce_flags = 0;
-  V3<R> sum = {0.f, 0.f, 0.f}, sum_mnee = {0.f, 0.f, 0.f};
+  V3<R> sum = {R(0), R(0), R(0)}, sum_mnee = {R(0), R(0), R(0)};
   uint32_t cur = 0, xy = 0;
   int s = 0, s_end = 0;
   PathKey key = {0u, P.seed, 0u, (uint32_t)P.rng};
   // the lane's task
   bool pending = false, finishing = false;   // finishing: the work item's last path has ended, its chunk sum waits for the task
-  V3<R> task_p = {0.f, 0.f, 0.f}, task_w = {0.f, 0.f, 0.f};
+  V3<R> task_p = {R(0), R(0), R(0)}, task_w = {R(0), R(0), R(0)};
   uint32_t task_sample = 0u;
   int task_bounce = 0, task_j = 0, task_i = -1;   // the attempt to run: light j, chain i (pt_mnee.hpp)
   uint32_t quiet_queries = 0u;
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(kBlock, RTX_MNEE_BATCHED_MIN_WAVES) void render_fus
     key.pixel = y * (uint32_t)P.width + x;
     s = (int)chunk * P.chunk_spp;
     s_end = s + P.chunk_spp < P.spp ? s + P.chunk_spp : P.spp;
-    sum = {0.f, 0.f, 0.f}; sum_mnee = {0.f, 0.f, 0.f};
+    sum = {R(0), R(0), R(0)}; sum_mnee = {R(0), R(0), R(0)};
     return s < s_end;
   };
   auto store_item = [&]() {
@@ -336,17 +335,17 @@ __global__ __launch_bounds__(kBlock, RTX_MNEE_BATCHED_MIN_WAVES) void render_fus
     bool started = false;
     if (go) {
       Hit<R> rec;
-      const bool hit = trace_closest<R, MODE>(sc, ps.ray, 0.001f, 1e9f, rec, st);
+      const bool hit = trace_closest<R, MODE>(sc, ps.ray, R(0.001), R(1e9), rec, st);
       if constexpr (MODE != MODE_FLAT) { if (hit && rec.tied) note_tied_item(P, counters, cur); }
       did = path_vertex_impl<R, true, MODE == MODE_TREE_UV && (LEAN & 32) == 0>(
           ps, hit, rec, sc, mats, P, key,
           [&](const Ray<R>& sr, R t_max, V3<R> contrib) {
-            const bool visible = !trace_occluded<R, MODE, true>(sc, sr, 0.001f, t_max, st);
+            const bool visible = !trace_occluded<R, MODE, true>(sc, sr, R(0.001), t_max, st);
             if (visible) ps.acc = ps.acc + contrib;
             return visible;
           },
           [&](V3<R> hp, V3<R> surf, int bounce) {
-            task_p = hp; task_w = (surf * ps.thr) * (1.0f / 3.14159265358979323846f);
+            task_p = hp; task_w = (surf * ps.thr) * (R(1) / R(3.14159265358979323846));
             task_sample = key.sample; task_bounce = bounce; task_j = 0; task_i = -1;
             MneeTracer<R, MODE> trace = {sc, st, extra_traces};
             pending = mnee_next_attempt(sc, mats, v3_to<double>(hp), key, bounce, task_j, task_i, trace);
