@@ -247,7 +247,8 @@ int rtx_render_device(rtx_ctx* ctx, const rtx_settings* settings, void* d_out_rg
  * a film gather of the previous frame).  It has no counterpart in the reference, whose GPUPathTracer::render is synchronous
  * (cuda_pathtracer.cu:375).  rtx_render_device_async puts the render on `hip_stream` - the caller's stream, taken as given: NULL
  * is HIP's default stream here, not the context's own, so that the caller can order its work behind the render - and
- * returns without waiting; the film is complete where the stream stands at that moment.  The fused
+ * returns without waiting; the film is complete where the stream stands at that moment (for that reason the first such call after
+ * the upload of a large scene waits for the reference-order tree, see rtx_upload_scene: it never renders ahead of it).  The fused
  * pipeline enqueues and returns at once; the queue-based pipeline reads its queue lengths back between kernels, so the call
  * returns when its last kernels are enqueued.  rtx_render_wait waits for that render and fills `stats` (may be NULL).  A context
  * holds ONE render in flight: any other render call on it first waits for the one pending.  Single-device contexts only. */

@@ -944,6 +944,7 @@ static int render_multi(rtx_ctx* c, const rtx_settings* s, float* host_out, void
     std::mutex m;
     std::condition_variable cv;
     bool enqueued = false;   // the share's kernels are on its stream (or it failed before that)
+    bool collected = false;  // ... and already waited for (a frame rendered ahead of the reference-order tree, see enqueue_share)
   };
   std::unique_ptr<Share[]> sh(new Share[n]);
   for (int k = 0; k < n; ++k) memset(&sh[k].st, 0, sizeof(rtx_stats));
@@ -958,13 +959,25 @@ static int render_multi(rtx_ctx* c, const rtx_settings* s, float* host_out, void
     if (!x->film.ensure((size_t)rows[k] * row_bytes)) { sh[k].rc = RTX_ERR_OUT_OF_MEMORY; sh[k].err = "film buffer"; return; }
     sh[k].rc = render_enqueue(x, &sk[k], nullptr, x->film.ptr, nullptr);
     if (sh[k].rc != RTX_OK) { sh[k].err = g_error; return; }
+    if (x->pending.optimistic) {
+      // A frame ahead of the reference-order tree: collecting it renders its tied work items again, so nothing - the copy to the
+      // host below, the gather - may be ordered behind the kernels that are on the stream now.  Collect first.
+      sh[k].rc = render_collect(x, &sh[k].st);
+      sh[k].collected = true;
+      if (sh[k].rc != RTX_OK) { sh[k].err = g_error; return; }
+    }
     if (host_out) {
       const hipError_t e = hipMemcpy2DAsync((char*)host_out + (size_t)k * row_bytes, (size_t)n * row_bytes, x->film.ptr, row_bytes, row_bytes, (size_t)rows[k], hipMemcpyDeviceToHost, x->stream);
       if (e != hipSuccess) { sh[k].rc = RTX_ERR_HIP; sh[k].err = std::string("film copy to the host: ") + hipGetErrorString(e); }
     }
   };
   auto finish_share = [&](int k) {    // -> its kernels (and its copy to the host) are done, its statistics read
-    if (rows[k] == 0 || !all[k]->pending.active) return;
+    if (rows[k] == 0) return;
+    if (sh[k].collected) {   // (only the copy to the host may still be on its way)
+      if (hipSetDevice(all[k]->device) != hipSuccess || hipStreamSynchronize(all[k]->stream) != hipSuccess) { if (sh[k].rc == RTX_OK) { sh[k].rc = RTX_ERR_HIP; sh[k].err = "waiting for the film copy failed"; } }
+      return;
+    }
+    if (!all[k]->pending.active) return;
     const int rc = render_collect(all[k], &sh[k].st);
     if (rc != RTX_OK && sh[k].rc == RTX_OK) { sh[k].rc = rc; sh[k].err = g_error; }
   };
@@ -1112,7 +1125,13 @@ int rtx_render_device(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* 
 int rtx_render_device_async(rtx_ctx* c, const rtx_settings* s, void* d_out_rgb, void* hip_stream) {
   if (!d_out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "d_out_rgb is NULL");
   if (c && c->multi) return fail(RTX_ERR_UNSUPPORTED, "the asynchronous render takes a single-device context (rtx_create)");
-  return guarded([&] { return render_enqueue(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, false, false, true); });
+  return guarded([&] {
+    // The film must be complete in stream order (the caller queues its own work behind the render), so this entry point never
+    // renders ahead of the reference-order tree - such a frame has work items rendered again when it is collected: it waits for
+    // the tree of a large scene here, once.
+    if (c && c->has_scene) { const int rc = need_tree(c); if (rc != RTX_OK) return rc; }
+    return render_enqueue(c, s, nullptr, d_out_rgb, (hipStream_t)hip_stream, false, false, true);
+  });
 }
 
 int rtx_render_wait(rtx_ctx* c, rtx_stats* stats) {

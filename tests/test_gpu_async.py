@@ -202,6 +202,68 @@ def test_render_before_the_reference_order_tree_arrives(pipeline, pkg, load_scen
     assert np.array_equal(got3.view(np.uint32), want3.view(np.uint32))
 
 
+def test_async_render_of_a_large_scene_is_complete_in_stream_order(pkg, load_scene, monkeypatch):
+    """rtx_render_device_async promises the film complete where the stream stands: work the caller queues behind it (here a copy)
+    must see the final film even when the call comes before the reference-order tree of a large scene has arrived - the call
+    waits for the tree instead of rendering ahead of it (a frame rendered ahead has work items rendered again at collection)."""
+    import torch
+    abi = pkg.abi
+    kw = dict(width=320, height=180, samples_per_pixel=8, max_depth=6, seed=8, pipeline=abi.PIPELINE_WAVEFRONT)
+    twins = _big_soup(pkg, load_scene, 300_000, duplicates=3_000)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def render(env):
+        for k in ("RTX_EAGER_TREE", "RTX_TREE_DELAY_MS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pkg.renderer.HipPathTracer(0) as pt:
+            pt.upload_scene(twins)
+            pt.set_camera(twins.camera(kw["width"], kw["height"]))
+            pt.set_settings(twins.settings(**kw))
+            out = torch.full((kw["height"], kw["width"], 3), -1.0, dtype=torch.float32, device="cuda:0")
+            pt.render_device_async(out.data_ptr(), stream)
+            behind = out.clone()              # queued behind the render, before it is collected
+            st = pt.render_wait()
+            return behind.cpu().numpy(), out.cpu().numpy(), st.flags
+
+    want, want_out, flags = render({"RTX_EAGER_TREE": "1"})
+    assert flags == 0 and np.array_equal(want.view(np.uint32), want_out.view(np.uint32))
+    behind, out, flags = render({"RTX_TREE_DELAY_MS": "800"})
+    assert flags == 0                                                   # (not rendered ahead of the tree)
+    assert np.array_equal(behind.view(np.uint32), want.view(np.uint32)) and np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+def test_multi_device_context_renders_before_the_reference_order_tree_arrives(pkg, load_scene, monkeypatch):
+    """rtx_create_multi with a large scene: the one background job finishes the reference-order tree and copies it to every device
+    of the context; frames rendered meanwhile repair their tied work items per device.  (One GPU listed twice: two contexts, two
+    copies, the peer-copy gather.)"""
+    abi = pkg.abi
+    kw = dict(width=320, height=180, samples_per_pixel=8, max_depth=6, seed=8, pipeline=abi.PIPELINE_WAVEFRONT)
+    twins = _big_soup(pkg, load_scene, 300_000, duplicates=3_000)
+
+    def render(device_ids, env):
+        for k in ("RTX_EAGER_TREE", "RTX_TREE_DELAY_MS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with (pkg.renderer.HipPathTracer(device_ids=device_ids) if device_ids else pkg.renderer.HipPathTracer(0)) as pt:
+            pt.upload_scene(twins)
+            pt.set_camera(twins.camera(kw["width"], kw["height"]))
+            pt.set_settings(twins.settings(**kw))
+            first = pt.render().copy()
+            flags = pt.last_stats.flags
+            second = pt.render().copy()
+            return first, flags, second, pt.last_stats.flags
+
+    want, flags, _, _ = render(None, {"RTX_EAGER_TREE": "1"})
+    assert flags == 0
+    first, flags, second, flags2 = render([0, 0], {"RTX_TREE_DELAY_MS": "1500"})
+    assert flags & abi.STAT_BEFORE_TREE and flags & abi.STAT_TIES_REPAIRED
+    assert np.array_equal(first.view(np.uint32), want.view(np.uint32))
+    assert flags2 == 0 and np.array_equal(second.view(np.uint32), want.view(np.uint32))
+
+
 def test_material_coherent_variant_gives_the_same_film(pkg, load_scene):
     """RTX_FUSED_REGROUP launches the variant of the lean flat path tracer whose lanes trade places by vertex class after every
     closest-hit query (an experiment kept for its measurement): another lane computes a path, the path is the same (to the rounding
