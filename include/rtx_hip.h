@@ -222,7 +222,8 @@ int rtx_multi_set_gather(rtx_ctx* ctx, int mode);
  * single-precision path tracer needs that tree only to decide exact ties in t the reference's way, so it renders at once: the work
  * items of a frame in which such ties occur are rendered again when the tree is there (rtx_stats::flags), every film is the one the
  * finished tree gives.  Whatever walks the reference-order tree itself - rtx_trace_closest*, double precision, the other render modes,
- * rtx_get_bvh_info, rtx_get_reference_bvh - waits for it.  A scene in which a primitive's box is flat along an axis is built the
+ * rtx_get_bvh_info, rtx_get_reference_bvh - waits for it, and so do rtx_render_device_async (its film is complete in stream order)
+ * and rtx_render_device_noalloc (a frame ahead of the tree needs a tie list and a second pass).  A scene in which a primitive's box is flat along an axis is built the
  * ordinary way (the reference cannot reach some such primitives, which the wide tree has to know), as is every scene when the
  * environment variable RTX_EAGER_TREE is set. */
 int rtx_upload_scene(rtx_ctx* ctx, const rtx_scene_desc* scene);

@@ -737,7 +737,7 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     std::string terr;
     int trc = c->scene.adopt_tree(false, terr);   // takes it over if it has arrived meanwhile
     if (trc == RTX_OK && c->scene.tree_pending()) {
-      if (f64 || whitted || bdpt || photon || mnee || bare) trc = c->scene.adopt_tree(true, terr);
+      if (f64 || whitted || bdpt || photon || mnee || bare || no_alloc) trc = c->scene.adopt_tree(true, terr);   // (no_alloc: a frame ahead of the tree needs a tie list and a repair pass)
       else optimistic = true;
     }
     if (trc != RTX_OK) { c->has_scene = false; return fail(trc, "reference-order tree: %s", terr.c_str()); }

@@ -79,6 +79,44 @@ def test_noalloc_render_walks_a_tree_and_refuses_the_queue_pipeline(pkg, load_sc
             pt.render_device_noalloc(b.data_ptr())
 
 
+def test_noalloc_render_of_a_large_scene_waits_for_the_reference_order_tree(pkg, load_scene, monkeypatch):
+    """A frame rendered ahead of the reference-order tree of a large scene needs a tie list (an allocation) and a repair pass: the
+    no-allocation render takes neither, it waits for the tree, with or without statistics, and gives the eager build's film."""
+    import copy
+    import torch
+    abi = pkg.abi
+    sd = copy.copy(load_scene("cornell_box_quad"))
+    sd._keep = []
+    soup = pkg.synthetic.triangle_soup(300_000, seed=9, extent=2.2, size=0.08, n_materials=5)
+    for k in ("v0", "v1", "v2"):
+        soup[k] += (0, 2.5, -2.5)
+    twin = soup[:3000].copy()                      # 3 000 triangles occur twice: exact ties in t
+    twin["material_id"] = (twin["material_id"] + 2) % 5
+    sd.triangle_array = np.concatenate([soup, twin])
+    W, H = 160, 90
+    kw = dict(width=W, height=H, samples_per_pixel=8, max_depth=6, seed=8, pipeline=abi.PIPELINE_FUSED)
+
+    def render(env, with_stats):
+        for k in ("RTX_EAGER_TREE", "RTX_TREE_DELAY_MS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pkg.renderer.HipPathTracer(0) as pt:
+            pt.upload_scene(sd)
+            pt.set_camera(sd.camera(W, H))
+            pt.set_settings(sd.settings(**kw))
+            out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+            st = pt.render_device_noalloc(out.data_ptr(), want_stats=with_stats)
+            assert st is None or st.flags == 0
+            torch.cuda.synchronize()
+            return out.cpu().numpy()
+
+    want = render({"RTX_EAGER_TREE": "1"}, True)
+    for with_stats in (True, False):
+        got = render({"RTX_TREE_DELAY_MS": "800"}, with_stats)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_noalloc_render_recorded_into_a_graph(pkg, load_scene):
     """The stated use of the entry point: with stats = NULL it puts nothing but kernels on the stream, so a caller can record it
     into a HIP graph.  The graph is replayed several times with eager work and synchronisations of the program in between; every
