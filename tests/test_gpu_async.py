@@ -234,12 +234,13 @@ def test_async_render_of_a_large_scene_is_complete_in_stream_order(pkg, load_sce
     assert np.array_equal(behind.view(np.uint32), want.view(np.uint32)) and np.array_equal(out.view(np.uint32), want.view(np.uint32))
 
 
-def test_multi_device_context_renders_before_the_reference_order_tree_arrives(pkg, load_scene, monkeypatch):
+@pytest.mark.parametrize("pipeline", ["queues", "fused"])
+def test_multi_device_context_renders_before_the_reference_order_tree_arrives(pipeline, pkg, load_scene, monkeypatch):
     """rtx_create_multi with a large scene: the one background job finishes the reference-order tree and copies it to every device
     of the context; frames rendered meanwhile repair their tied work items per device.  (One GPU listed twice: two contexts, two
     copies, the peer-copy gather.)"""
     abi = pkg.abi
-    kw = dict(width=320, height=180, samples_per_pixel=8, max_depth=6, seed=8, pipeline=abi.PIPELINE_WAVEFRONT)
+    kw = dict(width=320, height=180, samples_per_pixel=8, max_depth=6, seed=8, pipeline=abi.PIPELINE_WAVEFRONT if pipeline == "queues" else abi.PIPELINE_FUSED)
     twins = _big_soup(pkg, load_scene, 300_000, duplicates=3_000)
 
     def render(device_ids, env):
@@ -262,6 +263,34 @@ def test_multi_device_context_renders_before_the_reference_order_tree_arrives(pk
     assert flags & abi.STAT_BEFORE_TREE and flags & abi.STAT_TIES_REPAIRED
     assert np.array_equal(first.view(np.uint32), want.view(np.uint32))
     assert flags2 == 0 and np.array_equal(second.view(np.uint32), want.view(np.uint32))
+
+
+def test_a_scene_replaced_or_dropped_while_its_reference_order_tree_is_being_built(pkg, load_scene, monkeypatch):
+    """rtx_upload_scene again, or rtx_destroy, while the background job of the previous upload is still at work: the job is waited
+    for (it writes into buffers of the scene it belongs to), nothing of it reaches the new scene."""
+    abi = pkg.abi
+    big = _big_soup(pkg, load_scene, 300_000)
+    small = load_scene("cornell_box")
+    kw = dict(width=96, height=54, samples_per_pixel=8, max_depth=6, seed=3)
+    with pkg.renderer.HipPathTracer(0) as pt:
+        pt.upload_scene(small)
+        pt.set_camera(small.camera(96, 54))
+        pt.set_settings(small.settings(**kw))
+        want = pt.render().copy()
+    monkeypatch.setenv("RTX_TREE_DELAY_MS", "1000")
+    with pkg.renderer.HipPathTracer(0) as pt:
+        pt.upload_scene(big)                       # returns at once; its tree is a second away
+        pt.upload_scene(small)                     # replaces it
+        pt.set_camera(small.camera(96, 54))
+        pt.set_settings(small.settings(**kw))
+        got = pt.render().copy()
+        assert pt.last_stats.flags == 0 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert pt.bvh_info().ref_prims == 3        # the Cornell box's three spheres
+        pt.upload_scene(big)
+    # (the context was destroyed with the second job still running)
+    pt = pkg.renderer.HipPathTracer(0)
+    pt.upload_scene(big)
+    pt.close()
 
 
 def test_material_coherent_variant_gives_the_same_film(pkg, load_scene):
