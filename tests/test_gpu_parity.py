@@ -331,6 +331,7 @@ def test_bdpt_film_equals_oracle(name, mis, pkg, oracle, tracer, load_scene):
                                                         ("cornell_box", 1, 90000, 40, 0.12),   # not walked, and more bounding boxes than the GPU keeps in LDS
                                                         ("cornell_box", 1, 4000, 300, 0.5),     # more photons per estimate than a wave's LDS list holds: lists in device memory
                                                         ("cornell_box", 1, 2500, 100000, 0.45), # more than there are photons: every photon in reach is kept
+                                                        ("cornell_box", 1, 40, 5, 0.6), ("cornell_box", 1, 3, 2, 0.6),   # a handful of photons or none: the smallest trees the device build makes
                                                         ("soup_box", 1, 3000, 30, 0.3),         # cornell_box + 600 triangles: the instances that walk a BVH with an LDS stack
                                                         ("sphere_field", 1, 3000, 30, 0.3)])    # 14 spheres: flat render kernel, but the photon pass walks the tree (LDS stack sized from the scene)
 def test_pathphoton_film_equals_oracle(name, nee, photons, k, radius, pkg, oracle, tracer, load_scene, monkeypatch):
