@@ -1,4 +1,4 @@
-"""The synthetic BVH stress configuration (10 M triangles, BASELINE's fifth configuration) on the GPU, through the C ABI.
+"""The synthetic BVH stress configuration (10 M triangles, the fifth benchmark configuration) on the GPU, through the C ABI.
 
 (a) closest hits of 1 M incoherent rays and of the 1920x1080 pixel-centre rays: rtx_trace_closest (double precision, reference
     order) and the production walk in double precision must equal the REAL reference's table (hits/c5.npz: digest of every
