@@ -48,7 +48,10 @@ class ShardedFilms:
     receives into one [world, total] buffer and re-interleaves each film with one strided copy:
     packed row j of rank k is film row k + world * j."""
 
-    def __init__(self, shapes, rank: int, world: int, device, via_host: bool = False):
+    def __init__(self, shapes, rank: int, world: int, device, via_host: bool = False, collective=None):
+        # collective: whether gather() goes through torch.distributed at all; by default it does when there is more than one rank.
+        # True with world == 1 runs the same calls in a group of one (a one-GPU machine can then exercise the RCCL path).
+        self.collective = (world > 1) if collective is None else bool(collective)
         # via_host: the ranks meet over gloo (rehearsals on a machine with fewer GPUs than ranks): gloo takes host tensors only, so
         # the buffer is copied to host memory with a synchronous copy, gathered there, and copied back on rank 0.
         self.via_host = bool(via_host)
@@ -62,7 +65,7 @@ class ShardedFilms:
         for (h, w), off in zip(self.shapes, self.offs):
             rows = shard_rows(h, rank, world)
             self.local.append(self.send[off: off + rows * w * 3].view(rows, w, 3))
-        root = world > 1 and rank == 0
+        root = self.collective and rank == 0
         self.recv = torch.empty((world, self.total), dtype=torch.float32, device=device) if root else None
         self.full = [torch.empty((r * world, w, 3), dtype=torch.float32, device=device) for r, (_, w) in zip(self.rmax, self.shapes)] if root else None
 
@@ -71,7 +74,7 @@ class ShardedFilms:
 
     def gather(self):
         """-> the whole films [H, W, 3] on rank 0 (views of buffers this object keeps), None on the other ranks."""
-        if self.world == 1:
+        if not self.collective:
             return list(self.local)
         if self.via_host:
             send = self.send.cpu()   # synchronous: the kernels that fill the buffer have finished when it returns
