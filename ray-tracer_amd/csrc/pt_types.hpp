@@ -65,9 +65,10 @@ struct alignas(64) DLeaf {
 static_assert(sizeof(DLeaf) == 64, "leaf record");
 constexpr int kLeafMaxPrims = 1;
 constexpr int kWalkDone = 0x7fffffff;
-// Words of stack a walk of a tree of `levels` node levels can need: one three-word entry per level, and one to spare.
+// Words of stack a walk of a tree of `levels` node levels can need: one two-word entry per level, and one to spare.
 constexpr int walk_stack_slots(int levels) { return 2 * (levels + 1); }
-// Deepest eight-wide tree the kernels walk: its stack (120 words per lane) still fits the LDS of one 256-lane workgroup.  A soup of
+// Deepest eight-wide tree the kernels walk: its stack (80 words per lane, 80 KB for a 256-lane workgroup) is what the launch code
+// checks against the device's LDS per workgroup before every launch; a scene over that limit is refused with a message.  A soup of
 // 10 M triangles builds 8 levels; cuts at Morton code bits consume at least one bit of the 63 per level before ranges of equal
 // codes are halved, so only adversarial inputs get anywhere near.
 constexpr int kMaxWalkLevels = 39;
