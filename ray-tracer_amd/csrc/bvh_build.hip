@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void emit_level_kernel(int first, int count, c
           clo[0] = a.x; clo[1] = a.y; clo[2] = a.z; chi[0] = b.x; chi[1] = b.y; chi[2] = b.z;
           if (p >= ns && p < ns + nt) {
             const DTri<float>& t = tris[p - ns];
-            for (int j = 0; j < 3; ++j) { rec.v[j] = t.v0[j]; rec.v[3 + j] = t.v1[j]; rec.v[6 + j] = t.v2[j]; }
+            for (int j = 0; j < 3; ++j) { rec.v[j] = t.v0[j]; rec.v[3 + j] = t.v1[j] - t.v0[j]; rec.v[6 + j] = t.v2[j] - t.v0[j]; }   // v0 and the two edges from it
             rec.ref = p;
           } else {
             rec.ref = -2 - p;

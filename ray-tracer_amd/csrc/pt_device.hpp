@@ -399,8 +399,9 @@ template <class R, bool ANY> RTX_DEV bool walk_bounded(const DScene<R>& sc, cons
 //   walk8_leaf   fetches ONE leaf record and tests its primitive (a triangle in place; a sphere or a box through its
 //                table).
 // w.node is a node record's unit (>= 0), a leaf code ~unit (< 0) or kWalkDone.  A stack entry is the group of siblings still to
-// visit under one node, two words: the node's inner_base (where its children's records start), and  slots (3 bits each, next first) | remaining
-// count << 24 | n_inner << 28;  a child's code follows from its slot.  One entry per level at most, so levels + 1 entries always
+// visit under one node, two words: the node's inner_base (where its children's records start), and  up to seven nibbles (8 | slot, next
+// first; a nibble of 0 ends the group) | n_inner << 28  (any-hit walks, which take the children in slot order: one bit per child entered
+// | n_inner << 28);  a child's code follows from its slot.  One entry per level at most, so levels + 1 entries always
 // suffice.  A parked child is not re-tested against the interval the hits found meanwhile have shortened (its children /
 // primitives are).  A box is entered on a <= b: the tree's own grouping may make a box flat along an axis, which must not hide
 // its primitives.  On an exact tie in t the primitive later in the reference's leaf order wins, whatever the visiting order
@@ -420,15 +421,26 @@ RTX_DEV bool walk8_at_leaf(const Walk8& w) { return w.node < 0; }
 RTX_DEV uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
 RTX_DEV uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
-// Next parked child, or kWalkDone.
-RTX_DEV int walk8_pop(Walk8& w, LaneStack st) {
+// Next parked child, or kWalkDone.  SORTED: the entry holds nibbles, nearest child first; otherwise one bit per child entered,
+// taken lowest slot first.
+template <bool SORTED> RTX_DEV int walk8_pop(Walk8& w, LaneStack st) {
   if (w.sp == 0) return kWalkDone;
   const int e = 2 * (w.sp - 1);
   const int ib = st.get(e);
   const uint32_t pk = (uint32_t)st.get(e + 1);
-  const int slot = (int)(pk & 7u), cnt = (int)((pk >> 24) & 7u), ni = (int)(pk >> 28);
-  if (cnt <= 1) --w.sp;
-  else st.put(e + 1, (int)(((pk & 0x00ffffffu) >> 3) | ((uint32_t)(cnt - 1) << 24) | (pk & 0xf0000000u)));
+  const int ni = (int)(pk >> 28);
+  int slot;
+  if constexpr (SORTED) {
+    slot = (int)(pk & 7u);
+    const uint32_t rest = (pk & 0x0fffffffu) >> 4;
+    if (!(rest & 8u)) --w.sp;                        // the next nibble names no child: the group is used up
+    else st.put(e + 1, (int)(rest | (pk & 0xf0000000u)));
+  } else {
+    slot = __builtin_ctz(pk);                        // (an entry is kept only while one of its eight low bits is set)
+    const uint32_t rest = pk & (pk - 1u);
+    if (!(rest & 0xffu)) --w.sp;
+    else st.put(e + 1, (int)rest);
+  }
   return slot < ni ? ib + slot : ~(ib + slot);   // child k's record is unit inner_base + k; the leaf records follow the inner children
 }
 
@@ -456,7 +468,8 @@ template <bool SORTED = true> RTX_DEV void walk8_inner(const DScene<float>& sc, 
   const int n_inner = (int)((exps >> 24) & 15u);
   const int inner_base = (int)h0.w;   // child k's record is unit inner_base + k (k >= n_inner: a leaf record)
   uint32_t key[8];
-  int m = 0;   // children entered
+  uint32_t entered = 0u;                       // !SORTED: bit k = child k entered
+  constexpr uint32_t kNoChild = 0xfffffff0u;   // sorts behind every child entered; its low nibble says "no child"
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int sh = 8 * (k & 3);
@@ -465,10 +478,10 @@ template <bool SORTED = true> RTX_DEV void walk8_inner(const DScene<float>& sc, 
     const float b = fminf(fminf(fmaf((float)((fx[k >> 2] >> sh) & 0xffu), ax, bx), fmaf((float)((fy[k >> 2] >> sh) & 0xffu), ay, by)),
                           fminf(fmaf((float)((fz[k >> 2] >> sh) & 0xffu), az, bz), t_best));
     const bool ok = a <= b;
-    // sortable key: the entry distance (a positive float, whose bit pattern orders as an unsigned integer) with the slot in
-    // its three lowest bits
-    key[k] = ok ? ((__float_as_uint(a) & ~7u) | (uint32_t)k) : 0xffffffffu;
-    m += ok ? 1 : 0;
+    // sortable key: the entry distance (a positive float, whose bit pattern orders as an unsigned integer) with the nibble
+    // 8 | slot in its four lowest bits
+    if constexpr (SORTED) key[k] = ok ? ((__float_as_uint(a) & ~15u) | (8u | (uint32_t)k)) : kNoChild;
+    else entered |= ok ? (1u << k) : 0u;
   }
   // An unused slot (planes 255 and 0) is entered by no ray as long as 255 units make a difference to the slab distance.  They stop
   // doing so when the node is so small and so far from the ray's origin that 255 * ax is lost in the rounding of bx (on every axis,
@@ -478,21 +491,19 @@ template <bool SORTED = true> RTX_DEV void walk8_inner(const DScene<float>& sc, 
     const int last = (int)(exps >> 28);   // n_child - 1
 #pragma unroll
     for (int k = 2; k < 8; ++k)           // a node has at least two children
-      if (k > last && key[k] != 0xffffffffu) { key[k] = 0xffffffffu; --m; }
+      if (k > last) key[k] = kNoChild;
+    entered &= (2u << last) - 1u;
   }
   if constexpr (!SORTED) {
-    // slot order: the slots of the children entered, packed three bits each, lowest slot first
-    uint32_t slots = 0u;
-    int at = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { const bool ok = key[k] != 0xffffffffu; slots |= ok ? ((uint32_t)k << at) : 0u; at += ok ? 3 : 0; }
-    if (m >= 2) {
+    // slot order: the lowest slot entered is next, the others are parked as a bit mask
+    const uint32_t rest = entered & (entered - 1u);
+    if (rest) {
       const int e = 2 * w.sp;
-      st.put(e, inner_base); st.put(e + 1, (int)((slots >> 3) | ((uint32_t)(m - 1) << 24) | ((uint32_t)n_inner << 28)));
+      st.put(e, inner_base); st.put(e + 1, (int)(rest | ((uint32_t)n_inner << 28)));
       ++w.sp;
     }
-    if (m >= 1) { const int k = (int)(slots & 7u); w.node = k < n_inner ? inner_base + k : ~(inner_base + k); }
-    else w.node = walk8_pop(w, st);
+    if (entered) { const int k = __builtin_ctz(entered); w.node = k < n_inner ? inner_base + k : ~(inner_base + k); }
+    else w.node = walk8_pop<false>(w, st);
     return;
   }
   // sorting network on the keys, ascending (19 compare-exchanges of one min and one max each)
@@ -505,21 +516,26 @@ template <bool SORTED = true> RTX_DEV void walk8_inner(const DScene<float>& sc, 
   RTX_CX(2, 4) RTX_CX(3, 5)
   RTX_CX(3, 4)
 #undef RTX_CX
-  if (m >= 2) {   // park the siblings of the nearest child as one entry (slots beyond the count are never read)
-    const uint32_t slots = (key[1] & 7u) | ((key[2] & 7u) << 3) | ((key[3] & 7u) << 6) | ((key[4] & 7u) << 9) | ((key[5] & 7u) << 12) | ((key[6] & 7u) << 15) |
-                           ((key[7] & 7u) << 18);
+  if (key[1] & 8u) {   // park the siblings of the nearest child as one entry (a key that names no child leaves a nibble of 0)
+    // eight funnel shifts by one nibble: the low nibbles of key[1..7], then n_inner, pushed in at the top; key[1]'s ends at the bottom
+    uint32_t slots = 0u;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) slots = __builtin_amdgcn_alignbit(key[i], slots, 4);
+    slots = __builtin_amdgcn_alignbit((uint32_t)n_inner, slots, 4);
     const int e = 2 * w.sp;
-    st.put(e, inner_base); st.put(e + 1, (int)(slots | ((uint32_t)(m - 1) << 24) | ((uint32_t)n_inner << 28)));
+    st.put(e, inner_base); st.put(e + 1, (int)slots);
     ++w.sp;
   }
-  if (m >= 1) { const int k = (int)(key[0] & 7u); w.node = k < n_inner ? inner_base + k : ~(inner_base + k); }
-  else w.node = walk8_pop(w, st);
+  if (key[0] & 8u) { const int k = (int)(key[0] & 7u); w.node = k < n_inner ? inner_base + k : ~(inner_base + k); }
+  else w.node = walk8_pop<true>(w, st);
 }
 
-// Möller-Trumbore on in-place vertices (ref: engine/primitives.hpp:78-110); NaN vertices fail the first comparison.
+// Möller-Trumbore on a leaf record's triangle (ref: engine/primitives.hpp:78-110): v = the first vertex and the two edges from it,
+// v1 - v0 and v2 - v0, subtracted when the record was written (the same single-precision differences the test would take); NaN
+// entries fail the first comparison.
 RTX_DEV bool leaf_tri_t(const float* v, const Ray<float>& r, float t_min, float t_max, float& t, float& u, float& vv) {
   const V3<float> v0 = {v[0], v[1], v[2]};
-  const V3<float> e1 = V3<float>{v[3], v[4], v[5]} - v0, e2 = V3<float>{v[6], v[7], v[8]} - v0;
+  const V3<float> e1 = {v[3], v[4], v[5]}, e2 = {v[6], v[7], v[8]};
   const V3<float> h = cross(r.d, e2);
   const float a = dot(e1, h);
   const float f = 1.0f / a;
@@ -575,7 +591,7 @@ RTX_DEV void walk8_leaf_test(const DScene<float>& sc, const Ray<float>& r, float
 template <bool ANY> RTX_DEV void walk8_leaf(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, Walk8& w, LaneStack st) {
   walk8_leaf_test(sc, r, t_min, c, w, w.node);
   if (ANY && c.type >= 0) { w.node = kWalkDone; return; }
-  w.node = walk8_pop(w, st);
+  w.node = walk8_pop<!ANY>(w, st);
 }
 
 template <bool ANY> RTX_DEV bool walk8(const DScene<float>& sc, const Ray<float>& r, float t_min, Cand<float>& c, LaneStack st) {

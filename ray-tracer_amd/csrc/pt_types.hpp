@@ -53,7 +53,7 @@ struct alignas(64) DNode8 {
 };
 static_assert(sizeof(DNode8) == 64, "node record");
 constexpr int kNodeOriginBits = 21;
-// One leaf record is one unit: ONE primitive.  ref >= 0: a triangle with its vertices in place, ref = the primitive's number in
+// One leaf record is one unit: ONE primitive.  ref >= 0: a triangle in place (v = its first vertex, then the edges v1 - v0 and v2 - v0), ref = the primitive's number in
 // the reference's primitive list (spheres, then triangles, then boxes: engine/scene.hpp:496-533); ref == -1: nothing to test (a
 // primitive the reference can never hit); ref <= -2: a sphere or a box, primitive number -2 - ref, tested through its table.  A
 // record without a triangle has NaN vertices, which fail the triangle test.
