@@ -409,7 +409,9 @@ def roofline(cfg, abi, jobs, stats, world, n_jobs):
         r.update({"bound": "valu", "unit": "Gwave-inst/s", "peak": peak, "kernel": "wf_extend (closest-hit walk of the ray queue through the eight-wide tree)",
                   "peak_definition": "two wave64 instructions per SIMD per 4 cycles (dual issue) x 1024 SIMDs x 2.4 GHz",
                   "single_issue_rate": peak / 2, "measured_stream_rates": VALU_STREAM_RATES,
-                  "kernel_ms": ext_s * 1e3, "frame_ms": kern_s * 1e3, "achieved": None, "frac": None, "traffic": None, "lanes_active": None, "valu_busy": None})
+                  "kernel_ms": ext_s * 1e3, "frame_ms": kern_s * 1e3, "achieved": None, "frac": None, "traffic": None, "lanes_active": None, "valu_busy": None,
+                  # small launches (shards of a frame) run the any-hit walk of a turn beside the closest-hit walk: kernel_ms then includes shared time
+                  "walks_side_by_side": bool(first[0].flags & abi.STAT_WALKS_SIDE_BY_SIDE)})
         if ext_s > 0 and nodes > 0:
             alg = nodes * rec_b + prims * info.leaf_bytes
             hbm = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": alg / ext_s / 1e9, "frac": alg / ext_s / 1e9 / HBM_PEAK_GBPS,

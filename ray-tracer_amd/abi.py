@@ -112,7 +112,7 @@ PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
 MODE_WHITTED, MODE_PATHTRACE, MODE_BDPT, MODE_PATHPHOTON = 0, 1, 2, 6
 RNG_AUTO, RNG_PHILOX, RNG_PCG4D = 0, 1, 2
 GATHER_PEER_COPY, GATHER_RCCL = 0, 1
-STAT_BEFORE_TREE, STAT_TIES_REPAIRED, STAT_RENDERED_TWICE = 1, 2, 4
+STAT_BEFORE_TREE, STAT_TIES_REPAIRED, STAT_RENDERED_TWICE, STAT_WALKS_SIDE_BY_SIDE = 1, 2, 4, 8
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 

@@ -36,6 +36,17 @@ void WavefrontPool::release() {
   state.release(); queues.release(); control.release(); sort_tmp.release();
   for (hipEvent_t e : events) (void)hipEventDestroy(e);
   events.clear(); events_used = 0;
+  if (side) (void)hipStreamDestroy(side);
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
+  if (ev_join) (void)hipEventDestroy(ev_join);
+  side = nullptr; ev_fork = nullptr; ev_join = nullptr;
+}
+bool WavefrontPool::ensure_side() {
+  if (side && ev_fork && ev_join) return true;
+  if (!side && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
+  if (!ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) { ev_fork = nullptr; return false; }
+  if (!ev_join && hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) { ev_join = nullptr; return false; }
+  return true;
 }
 bool WavefrontPool::mark(hipStream_t stream) {
   if (events_used == events.size()) {

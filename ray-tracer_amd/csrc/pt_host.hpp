@@ -198,6 +198,11 @@ struct WavefrontPool {
   std::vector<hipEvent_t> events;
   size_t events_used = 0;
   bool timing_ok = true;             // every mark of the last render succeeded (else its pairs would be mismatched)
+  // The any-hit walk of a turn runs on a stream of its own, beside the closest-hit walk (the two are independent): made at first use
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = false;              // this render runs the two walks of a turn side by side
+  bool ensure_side();
   bool mark(hipStream_t stream);     // record the next event on `stream`
   double timed_seconds() const;      // sum over the pairs (0 if a mark failed); call after the stream has been synchronised
   void release();

@@ -64,7 +64,7 @@ using namespace rtx;
 // ------------------------------------------------------------------------------------------
 // Samples and work items (pixel, sample chunk) a lane of a fused launch handles at least, which sizes the grid (see the launch in
 // render_enqueue).
-constexpr unsigned long long kFusedSamplesPerLane = 32, kFusedMinItemsPerLane = 3;
+constexpr unsigned long long kFusedSamplesPerLane = 32, kFusedMinItemsPerLane = 3, kFusedRounds = 16;
 constexpr size_t kScratchBytes = 64ull << 20;
 constexpr size_t kScratchHeader = 256;   // the counters, ahead of the chunk sums
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
@@ -598,6 +598,11 @@ static int render_collect(rtx_ctx* c, rtx_stats* stats) {
   HIP_TRY(hipStreamSynchronize(pd.stream));
   rtx_stats st = pd.st;
   const DCounters hc = *c->h_counters;
+  // the times of this pass, read before a repair pass records the same events again
+  float ms_render = 0.f, ms_main = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms_render, c->ev0, c->ev1));
+  HIP_TRY(hipEventElapsedTime(&ms_main, c->ev0, c->evm));
+  if (pd.wavefront) { st.seconds_extend = c->wf.timed_seconds(); if (c->wf.overlap) st.flags |= RTX_STAT_WALKS_SIDE_BY_SIDE; }
   if (pd.optimistic && hc.ties > 0) {
     // Ties in t were decided without the reference's leaf order: wait for that order, then render the work items they occurred in
     // again (a few dozen of the 33 M of a 1080p frame at 64 spp); if there were more than the list holds, the whole frame.
@@ -625,15 +630,11 @@ static int render_collect(rtx_ctx* c, rtx_stats* stats) {
     }
   }
   if (pd.optimistic) st.flags |= RTX_STAT_BEFORE_TREE;
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   st.samples = hc.samples; st.rays_closest = hc.closest; st.rays_shadow = hc.shadow; st.segments = hc.segments;
   if (pd.photon_map_reused) st.rays_closest += c->ph_map.closest;   // the queries this film's photon map was traced with, made by an earlier call
   st.nodes_visited = hc.nodes_visited; st.prims_tested = hc.prims_tested;
-  if (pd.wavefront) st.seconds_extend = c->wf.timed_seconds();
-  st.seconds_render = ms * 1e-3;
-  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->evm));
-  st.seconds_main_kernel = ms * 1e-3;
+  st.seconds_render = ms_render * 1e-3;
+  st.seconds_main_kernel = ms_main * 1e-3;
   st.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - pd.wall0).count();
   st.pipeline_used = (uint32_t)pd.pipeline;
   st.precision_used = pd.f64 ? RTX_PRECISION_F64 : RTX_PRECISION_F32;
@@ -823,7 +824,12 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     const unsigned long long one_item_each = (items + kBlock - 1) / kBlock, resident = (unsigned long long)c->n_cus * blocks_per_cu;
     unsigned long long per_lane = 0ull;   // 0 = the resident grid
     if (!bdpt && !photon && !whitted) {
-      per_lane = std::max<unsigned long long>(kFusedMinItemsPerLane, (kFusedSamplesPerLane + (unsigned long long)P.chunk_spp - 1ull) / (unsigned long long)P.chunk_spp);
+      const unsigned long long enough = (kFusedSamplesPerLane + (unsigned long long)P.chunk_spp - 1ull) / (unsigned long long)P.chunk_spp;   // items that hold kFusedSamplesPerLane samples
+      per_lane = std::max<unsigned long long>(kFusedMinItemsPerLane, enough);
+      // A small launch (a shard of a frame) would have few rounds of such workgroups, and its last, partly filled round would be a
+      // large share of it: fewer items per lane then, down to `enough`, as long as the grid has fewer than kFusedRounds rounds.
+      // 1080p Cornell box at 1024 spp, every 8th row: 24.3 -> 22.7 ms; every 4th: 44.7 -> 43.4; every 2nd and the whole frame: as before.
+      per_lane = std::min(per_lane, std::max(enough, items / (resident * (unsigned long long)kBlock * kFusedRounds)));
       if (const char* e = std::getenv("RTX_ITEMS_PER_LANE")) { const long v = std::atol(e); if (v >= 0 && v <= 4096) per_lane = (unsigned long long)v; }   // experiments
     } else {
       // PathPhoton: a sample costs many times a plain one (a density estimate per Lambertian vertex), a few per lane are enough:

@@ -87,6 +87,7 @@ constexpr int kLeafBatch = RTX_LEAF_BATCH;
 #endif
 
 
+constexpr uint32_t kOverlapBelowSlots = 24u << 20;   // launches of fewer path slots run the two walks of a turn side by side (wavefront_render)
 #ifndef RTX_POOL_MULT
 #define RTX_POOL_MULT 128   // path slots per resident lane (180 B each: 12 GB at most on 256 CUs); 10 M triangles at 1080p x 64 spp: 16: 839 ms, 32: 762, 64 and up (every work item in flight): 721
 #endif
@@ -618,13 +619,21 @@ template <int MODE> void launch_turn_kernels(const DScene<float>& sc, const DCam
     } else if (lds_mats) hipLaunchKernelGGL((wf_shade<MODE, true>), g, bs, mat_lds, stream, sc, cam, P, A, ctl, *turn, partial, banks, shade_order);
     else hipLaunchKernelGGL((wf_shade<MODE, false>), g, bs, 0, stream, sc, cam, P, A, ctl, *turn, partial, banks, shade_order);
     if (sorted) sort_queue(0, turn->sh, 1);
-    hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, turn->sh, partial, stack_levels, sorted ? A.order_out : nullptr);
+    if (pool.overlap) {   // the any-hit walk on the side stream, behind the shade kernel; the closest-hit walk below runs beside it
+      (void)hipEventRecord(pool.ev_fork, stream);
+      (void)hipStreamWaitEvent(pool.side, pool.ev_fork, 0);
+      hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, pool.side, sc, A, ctl, turn->sh, partial, stack_levels, nullptr);
+      (void)hipEventRecord(pool.ev_join, pool.side);
+    } else {
+      hipLaunchKernelGGL((wf_connect<MODE>), gw, b, walk_lds, stream, sc, A, ctl, turn->sh, partial, stack_levels, sorted ? A.order_out : nullptr);
+    }
     launches += 2;
   }
   if (sorted) sort_queue(q_out, n_out, 0);
   if (!pool.mark(stream)) pool.timing_ok = false;   // an event could not be made or recorded: this render reports no traversal time
   hipLaunchKernelGGL((wf_extend<MODE>), gw, b, walk_lds, stream, sc, A, ctl, n_out, stack_levels, counters, sorted ? A.order_out : A.q[q_out], P);
   if (!pool.mark(stream)) pool.timing_ok = false;
+  if (pool.overlap && turn) (void)hipStreamWaitEvent(stream, pool.ev_join, 0);   // the next kernel on `stream` needs both walks
   ++launches;
 }
 
@@ -695,6 +704,15 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   // (experiments only; films do not depend on it).  The ray sort and the material sort share the key / order arrays: the shade
   // kernel's order is used up before the ray sort of the same turn writes them again.
   pool.sort_materials = getenv("RTX_MATERIAL_SORT") != nullptr;
+  // The two tree walks of a turn - closest hit for the ray queue, any hit for the shadow queue - do not depend on each other.  In
+  // a small launch the end of a persistent walk, when most waves have run out of rays, is a large share of its time: then the
+  // any-hit walk goes to a stream of its own and the two run side by side, each filling the other's tail (10 M triangles, 64 spp,
+  // every 8th row of a 1080p frame: 81.8 -> 67.7 ms; every 4th: 128.1 -> 113.3; every 2nd: 217.3 -> 204.0; the whole frame 389 ->
+  // 383).  Large launches keep them one after the other, so that each kernel's time can be measured on its own.
+  // RTX_WALK_OVERLAP=0 / 1 forces one or the other (films do not depend on it).
+  pool.overlap = n_slots < kOverlapBelowSlots;
+  if (const char* e = getenv("RTX_WALK_OVERLAP")) pool.overlap = atoi(e) != 0;
+  pool.overlap = pool.overlap && !pool.sort_rays && pool.ensure_side();
   if (pool.sort_rays || pool.sort_materials) {
     size_t bytes = 0;
     if (rocprim::radix_sort_pairs(nullptr, bytes, A.key_in, A.key_out, A.order_in, A.order_out, (size_t)n_slots, 0u, kSortKeyBits, stream) != hipSuccess ||

@@ -2,7 +2,7 @@
 """A/B timing of library builds on one box: renders a configuration with each shared library given (paths; "-" = the tree's own)
 through the handful of entry points every build has, so that older builds can be compared too.
 Usage: python scripts/ab_render.py c2|c2mnee|c5 [spp] -- lib1 lib2 ...      One JSON line per library, best of three renders.
-(c2mnee: the Cornell box with use_mnee = 1, 16 spp.)"""
+(c2mnee: the Cornell box with use_mnee = 1, 16 spp.)  AB_SHARDS=N in the environment renders shard 0 of N (every N-th row)."""
 import ctypes as C
 import json
 import os
@@ -29,7 +29,7 @@ out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
 desc = sd.desc()
 cam = sd.camera(W, H)
 st = sd.settings(width=W, height=H, samples_per_pixel=spp, max_depth=depth, use_nee=1, use_mis=1, seed=1234, mode=abi.MODE_PATHTRACE, precision=abi.PRECISION_F32,
-                 use_mnee=1 if cfg == "c2mnee" else 0)
+                 use_mnee=1 if cfg == "c2mnee" else 0, shard_index=0, shard_count=int(os.environ.get("AB_SHARDS", "1")))
 first = None
 for path in libs:
     p = abi.LIB_PATH if path == "-" else os.path.join(ROOT, path)
@@ -52,7 +52,7 @@ for path in libs:
             best = s
     digest = float(out.double().sum().item())
     first = digest if first is None else first
-    print(json.dumps({"lib": path, "config": cfg, "spp": spp, "frame_ms": best.seconds_render * 1e3, "main_kernel_ms": best.seconds_main_kernel * 1e3,
+    print(json.dumps({"lib": path, "config": cfg, "spp": spp, "shards": int(os.environ.get("AB_SHARDS", "1")), "frame_ms": best.seconds_render * 1e3, "main_kernel_ms": best.seconds_main_kernel * 1e3,
                       "closest_hit_kernel_ms": best.seconds_extend * 1e3, "msamples_per_s": best.samples / best.seconds_render / 1e6,
                       "film_sum_equals_first": digest == first}), flush=True)
     lib.rtx_destroy(ctx)

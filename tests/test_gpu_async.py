@@ -64,6 +64,11 @@ def test_async_render_equals_synchronous_render(pkg, load_scene):
         pt.close()
 
 
+def _tree_flags(pkg, st):
+    """rtx_stats.flags without the bit that only says how the queue pipeline scheduled its two walks."""
+    return st.flags & ~pkg.abi.STAT_WALKS_SIDE_BY_SIDE
+
+
 def _queue_film(pkg, sd, env, **kw):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
@@ -95,6 +100,20 @@ def test_a_smaller_pool_and_material_queues_give_the_same_film(pkg, load_scene):
     film, st = _queue_film(pkg, sd, {"RTX_MATERIAL_SORT": "1"}, **kw)
     assert np.array_equal(film.view(np.uint32), want.view(np.uint32))
     assert (st.samples, st.rays_closest, st.rays_shadow, st.segments) == (st0.samples, st0.rays_closest, st0.rays_shadow, st0.segments)
+
+
+def test_the_two_walks_of_a_turn_side_by_side_or_one_after_the_other(pkg, load_scene):
+    """A small frame runs the any-hit walk of every turn on a stream of its own, beside the closest-hit walk (the statistics say
+    so); RTX_WALK_OVERLAP=0 puts them one after the other again.  Same film, same counters."""
+    abi = pkg.abi
+    sd = soup_scene(pkg, load_scene, n=60000)
+    kw = dict(width=640, height=360, samples_per_pixel=16, max_depth=6, seed=2)
+    beside, st1 = _queue_film(pkg, sd, {}, **kw)
+    serial, st0 = _queue_film(pkg, sd, {"RTX_WALK_OVERLAP": "0"}, **kw)
+    assert st1.flags & abi.STAT_WALKS_SIDE_BY_SIDE and not st0.flags & abi.STAT_WALKS_SIDE_BY_SIDE
+    assert np.array_equal(beside.view(np.uint32), serial.view(np.uint32))
+    assert (st1.samples, st1.rays_closest, st1.rays_shadow, st1.segments) == (st0.samples, st0.rays_closest, st0.rays_shadow, st0.segments)
+    assert st1.rays_shadow > 0 and st1.seconds_extend > 0
 
 
 def test_rccl_gather_of_a_multi_device_context(pkg, load_scene):
@@ -163,7 +182,7 @@ def test_render_before_the_reference_order_tree_arrives(pipeline, pkg, load_scen
                 pt.set_camera(sd.camera(kw["width"], kw["height"]))
                 pt.set_settings(sd.settings(**kw))
                 film = pt.render().copy()
-                flags = pt.last_stats.flags
+                flags = _tree_flags(pkg, pt.last_stats)
                 more = after(pt) if after else None
                 return film, flags, more
         finally:
@@ -180,7 +199,7 @@ def test_render_before_the_reference_order_tree_arrives(pipeline, pkg, load_scen
         info = pt.bvh_info()                 # waits for the tree
         assert info.ref_prims == 300_002 and info.build_seconds > 0   # the soup and the two spheres of the box
         film = pt.render().copy()
-        return film, pt.last_stats.flags
+        return film, _tree_flags(pkg, pt.last_stats)
     got, flags, (again, flags2) = render(plain, {"RTX_TREE_DELAY_MS": "1500"}, second)
     assert flags == abi.STAT_BEFORE_TREE                                 # rendered without the tree, and no tie occurred
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
@@ -225,7 +244,7 @@ def test_async_render_of_a_large_scene_is_complete_in_stream_order(pkg, load_sce
             pt.render_device_async(out.data_ptr(), stream)
             behind = out.clone()              # queued behind the render, before it is collected
             st = pt.render_wait()
-            return behind.cpu().numpy(), out.cpu().numpy(), st.flags
+            return behind.cpu().numpy(), out.cpu().numpy(), _tree_flags(pkg, st)
 
     want, want_out, flags = render({"RTX_EAGER_TREE": "1"})
     assert flags == 0 and np.array_equal(want.view(np.uint32), want_out.view(np.uint32))
@@ -253,9 +272,9 @@ def test_multi_device_context_renders_before_the_reference_order_tree_arrives(pi
             pt.set_camera(twins.camera(kw["width"], kw["height"]))
             pt.set_settings(twins.settings(**kw))
             first = pt.render().copy()
-            flags = pt.last_stats.flags
+            flags = _tree_flags(pkg, pt.last_stats)
             second = pt.render().copy()
-            return first, flags, second, pt.last_stats.flags
+            return first, flags, second, _tree_flags(pkg, pt.last_stats)
 
     want, flags, _, _ = render(None, {"RTX_EAGER_TREE": "1"})
     assert flags == 0
@@ -284,7 +303,7 @@ def test_a_scene_replaced_or_dropped_while_its_reference_order_tree_is_being_bui
         pt.set_camera(small.camera(96, 54))
         pt.set_settings(small.settings(**kw))
         got = pt.render().copy()
-        assert pt.last_stats.flags == 0 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert _tree_flags(pkg, pt.last_stats) == 0 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
         assert pt.bvh_info().ref_prims == 3        # the Cornell box's three spheres
         pt.upload_scene(big)
     # (the context was destroyed with the second job still running)
