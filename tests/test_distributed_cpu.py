@@ -60,7 +60,7 @@ def test_gather_film_world_one_is_identity(pkg):
     assert [parallel.shard_rows(13, r, 4) for r in range(4)] == [4, 3, 3, 3]
 
 
-def _sharded_worker(rank, world, port, shapes, out_path, via_host=False):
+def _sharded_worker(rank, world, port, shapes, out_path, via_host=False, collective=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     import rtx_pkg
@@ -69,7 +69,7 @@ def _sharded_worker(rank, world, port, shapes, out_path, via_host=False):
     parallel = importlib.import_module("raytracer_amd.parallel")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        films = parallel.ShardedFilms(shapes, rank, world, "cpu", via_host=via_host)
+        films = parallel.ShardedFilms(shapes, rank, world, "cpu", via_host=via_host, collective=collective)
         for step in range(2):   # a second step reuses every buffer
             for i, ((h, w), local) in enumerate(zip(shapes, films.local)):
                 whole = _pattern(h, w, i, step)
@@ -91,12 +91,14 @@ def _pattern(h, w, film, step):
     return (torch.arange(h * w * 3, dtype=torch.float32).reshape(h, w, 3) + 1000.0 * film + 0.5 * step)
 
 
-@pytest.mark.parametrize("world,via_host", [(2, False), (3, False), (2, True)])   # via_host: the rehearsal path (films staged through host memory for gloo)
-def test_sharded_films_gather_several_films_in_one_exchange(world, via_host, pkg, tmp_path):
+# via_host: the rehearsal path (films staged through host memory for gloo); collective with one rank: a group of one goes through
+# the collective all the same (what a one-GPU machine runs of the RCCL path)
+@pytest.mark.parametrize("world,via_host,collective", [(2, False, None), (3, False, None), (2, True, None), (1, False, True), (1, True, True)])
+def test_sharded_films_gather_several_films_in_one_exchange(world, via_host, collective, pkg, tmp_path):
     shapes = [(12, 5), (13, 4), (2, 3)]   # equal shares, unequal shares, fewer rows than ranks (world 3)
     out = str(tmp_path / "ok.txt")
-    port = 31500 + (os.getpid() % 2000) + world + (7 if via_host else 0)
-    mp.spawn(_sharded_worker, args=(world, port, shapes, out, via_host), nprocs=world, join=True)
+    port = 31500 + (os.getpid() % 2000) + world + (7 if via_host else 0) + (11 if collective else 0)
+    mp.spawn(_sharded_worker, args=(world, port, shapes, out, via_host, collective), nprocs=world, join=True)
     assert open(out).read() == "ok"
 
 
