@@ -147,7 +147,7 @@ typedef struct rtx_settings {
  * ties, so the call waited for the tree and rendered those work items again with the reference's tie order (the other counters and
  * times of the statistics are the first pass's; seconds_total covers everything).  RTX_STAT_RENDERED_TWICE: there were more of
  * them than the list holds (65 536), and the whole frame was rendered again.  RTX_STAT_WALKS_SIDE_BY_SIDE (queue pipeline): the
- * frame was small enough (fewer than 24 Mi path slots) for the closest-hit and the any-hit walk of every turn to run side by side on
+ * frame was small enough (fewer than 48 Mi path slots) for the closest-hit and the any-hit walk of every turn to run side by side on
  * two streams; seconds_extend then includes time the closest-hit kernel shared the device with the other walk. */
 enum { RTX_STAT_BEFORE_TREE = 1, RTX_STAT_TIES_REPAIRED = 2, RTX_STAT_RENDERED_TWICE = 4, RTX_STAT_WALKS_SIDE_BY_SIDE = 8 };
 typedef struct rtx_stats {

@@ -65,6 +65,7 @@ using namespace rtx;
 // Samples and work items (pixel, sample chunk) a lane of a fused launch handles at least, which sizes the grid (see the launch in
 // render_enqueue).
 constexpr unsigned long long kFusedSamplesPerLane = 32, kFusedMinItemsPerLane = 3, kFusedRounds = 16;
+constexpr int kWfTargetChunks = 64;   // chunks the queue pipeline cuts a pixel's sample sum into (render_enqueue); the fused kernels: 16
 constexpr size_t kScratchBytes = 64ull << 20;
 constexpr size_t kScratchHeader = 256;   // the counters, ahead of the chunk sums
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
@@ -685,7 +686,7 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
   P.use_nee = s->use_nee != 0; P.use_mis = s->use_mis != 0; P.use_gradient = s->use_background_gradient != 0;
   P.shard_index = s->shard_index; P.shard_count = sc_n;
   P.rows = rtx_shard_rows(s->height, s->shard_index, sc_n);
-  // Fixed chunking of the sample sum (a function of spp only) keeps the film bit-identical
+  // Fixed chunking of the sample sum (a function of spp and the pipeline only) keeps the film bit-identical
   // for any grid size or shard count.
   int target_chunks = std::min(P.spp, 16);
   P.chunk_spp = (P.spp + target_chunks - 1) / target_chunks;
@@ -725,6 +726,18 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
   // enough for the linear / flat intersection stay fused (no queue traffic, measured 2-3x faster).
   int pipeline = s->pipeline;
   if (pipeline == RTX_PIPELINE_AUTO) pipeline = (!f64_req && !whitted && !bdpt && !photon && !mnee && c->scene.n_prims > kLinearMaxPrims) ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED;
+  if (pipeline == RTX_PIPELINE_WAVEFRONT) {
+    // The queue pipeline cuts the sample sum finer: a path slot renders the samples of its work item one after the other, so the
+    // number of turns (and with it the number of launches, each with a start and an end at which the device is not full) follows
+    // the samples per item.  10 M triangles, 1080p, 64 spp, chunks of 4 / 2 / 1 samples: 389.9 / 371.5 / 373.9 ms; every 8th row of
+    // that frame: 67.7 / 58.2 / 52.7 ms.  The pool holds the items of a 1080p frame at 32 spp at once; beyond, slots take new items
+    // as they finish theirs.  (Still a function of spp alone: films do not depend on shards or grids.  RTX_WF_CHUNKS: experiments.)
+    int target = kWfTargetChunks;
+    if (const char* e = std::getenv("RTX_WF_CHUNKS")) target = std::max(1, std::atoi(e));
+    target = std::min(P.spp, target);
+    P.chunk_spp = (P.spp + target - 1) / target;
+    P.n_chunks = (P.spp + P.chunk_spp - 1) / P.chunk_spp;
+  }
   if (pipeline == RTX_PIPELINE_WAVEFRONT && photon) return fail(RTX_ERR_UNSUPPORTED, "the PathPhoton mode is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && bdpt) return fail(RTX_ERR_UNSUPPORTED, "the BDPT mode is implemented by the fused pipeline only");
   if (pipeline == RTX_PIPELINE_WAVEFRONT && whitted) return fail(RTX_ERR_UNSUPPORTED, "the Whitted mode is implemented by the fused pipeline only");

@@ -87,7 +87,7 @@ constexpr int kLeafBatch = RTX_LEAF_BATCH;
 #endif
 
 
-constexpr uint32_t kOverlapBelowSlots = 24u << 20;   // launches of fewer path slots run the two walks of a turn side by side (wavefront_render)
+constexpr uint32_t kOverlapBelowSlots = 48u << 20;   // launches of fewer path slots run the two walks of a turn side by side (wavefront_render)
 #ifndef RTX_POOL_MULT
 #define RTX_POOL_MULT 128   // path slots per resident lane (180 B each: 12 GB at most on 256 CUs); 10 M triangles at 1080p x 64 spp: 16: 839 ms, 32: 762, 64 and up (every work item in flight): 721
 #endif
@@ -707,8 +707,8 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   // The two tree walks of a turn - closest hit for the ray queue, any hit for the shadow queue - do not depend on each other.  In
   // a small launch the end of a persistent walk, when most waves have run out of rays, is a large share of its time: then the
   // any-hit walk goes to a stream of its own and the two run side by side, each filling the other's tail (10 M triangles, 64 spp,
-  // every 8th row of a 1080p frame: 81.8 -> 67.7 ms; every 4th: 128.1 -> 113.3; every 2nd: 217.3 -> 204.0; the whole frame 389 ->
-  // 383).  Large launches keep them one after the other, so that each kernel's time can be measured on its own.
+  // every 8th row of a 1080p frame: 56.0 -> 52.3 ms; every 4th: 100.8 -> 97.8; every 2nd and the whole frame: no gain, 189.1 -> 190.1
+  // and 374.1 -> 375.8).  Large launches keep them one after the other, so that each kernel's time can be measured on its own.
   // RTX_WALK_OVERLAP=0 / 1 forces one or the other (films do not depend on it).
   pool.overlap = n_slots < kOverlapBelowSlots;
   if (const char* e = getenv("RTX_WALK_OVERLAP")) pool.overlap = atoi(e) != 0;
