@@ -89,7 +89,7 @@ constexpr int kLeafBatch = RTX_LEAF_BATCH;
 
 constexpr uint32_t kOverlapBelowSlots = 48u << 20;   // launches of fewer path slots run the two walks of a turn side by side (wavefront_render)
 #ifndef RTX_POOL_MULT
-#define RTX_POOL_MULT 128   // path slots per resident lane (180 B each: 12 GB at most on 256 CUs); 10 M triangles at 1080p x 64 spp: 16: 839 ms, 32: 762, 64 and up (every work item in flight): 721
+#define RTX_POOL_MULT 256   // path slots per resident lane (180 B each: 24 GB at most on 256 CUs); 10 M triangles at 1080p x 64 spp (133 M work items of one sample): 16: 440 ms, 32: 409, 64: 389, 128: 374, 256 (every work item in flight): 364
 #endif
 constexpr int kWfArrays = 6 + 3 + 3 + 3 + 1 + 7 + 3 + 2 + 2 + 1 + 7 + 3 + 4;   // 4-byte arrays of n_slots entries
 
@@ -659,9 +659,9 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   for (int count : {sc.n_spheres, sc.n_planes, sc.n_tris, sc.n_boxes, sc.n_quads, sc.n_disks})
     if (count > kIdMask) { err = "the queue pipeline indexes at most 2^28 primitives of one type"; return RTX_ERR_UNSUPPORTED; }
   // Pool size: enough slots to keep every work item in flight if memory allows (RTX_POOL_MULT slots per resident lane at most,
-  // kWfArrays * 4 bytes each: 6.0 GB for a 1080p frame at 64 spp).  A device that cannot give that much - shared, or holding a large
-  // scene - gets a pool of half the size, and so on down to 16 slots per lane (measured on the 10 M-triangle frame: 128: 721 ms, 32:
-  // 762, 16: 839); the environment variable RTX_POOL_MULT caps the first try.
+  // kWfArrays * 4 bytes each: 24 GB for a 1080p frame at 64 spp).  A device that cannot give that much - shared, or holding a large
+  // scene - gets a pool of half the size, and so on down to 16 slots per lane (measured on the 10 M-triangle frame: 256: 364 ms,
+  // 128: 374, 64: 389, 32: 409, 16: 440); the environment variable RTX_POOL_MULT caps the first try.
   if (!pool.control.ensure(sizeof(WfShared)) || !pool.queues.ensure((size_t)all_items * 3 * sizeof(float))) { err = "pool allocation (chunk sums)"; return RTX_ERR_OUT_OF_MEMORY; }
   unsigned long long mult = (unsigned long long)RTX_POOL_MULT;
   if (const char* e = getenv("RTX_POOL_MULT")) { const long v = atol(e); if (v >= 1 && (unsigned long long)v < mult) mult = (unsigned long long)v; }
