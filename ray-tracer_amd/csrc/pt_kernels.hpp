@@ -49,13 +49,14 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #endif
 // The lean flat instances (see LEAN below) need fewer registers.  With a grid of exactly the resident workgroups they were best at 6
 // waves per SIMD (3: 310.8 ms, 4: 309.7, 5: 298.9, 6: 292.3, 7: 296.1, 8: 330.4 on the 1080p Cornell box); with many short
-// workgroups (rtx_api.cpp) one more wave pays: 5: 167.9 ms, 6: 168.0, 7: 163.8, 8: 164.0 (800 x 800 x 128, two scenes: 15.2 / 14.6 /
-// 14.7 / 14.7).
+// workgroups (rtx_api.cpp) more waves pay: 5: 167.9 ms, 6: 168.0, 7: 163.8, 8: 164.0 (800 x 800 x 128, two scenes: 15.2 / 14.6 /
+// 14.7 / 14.7) when that grid was introduced; measured again on the kernels as they are now, 7: 166.0 ms, 8 (64 registers, ten of
+// them spilled): 160.5, and 8.62 / 6.86 -> 8.38 / 6.77 ms for the two 800 x 800 scenes.
 #ifndef RTX_LEAN_ENV_MIN_WAVES
 #define RTX_LEAN_ENV_MIN_WAVES 6   // lean instance that keeps the environment map
 #endif
 #ifndef RTX_LEAN_MIN_WAVES
-#define RTX_LEAN_MIN_WAVES 7
+#define RTX_LEAN_MIN_WAVES 8
 #endif
 #ifndef RTX_TREE_MIN_WAVES
 #define RTX_TREE_MIN_WAVES 3   // single-precision tree-walking instances: they sit at the 168-VGPR edge of 3 waves per SIMD
