@@ -61,6 +61,9 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 #ifndef RTX_TREE_MIN_WAVES
 #define RTX_TREE_MIN_WAVES 5   // single-precision tree-walking path instances (earth_demo 4K x 256 spp: 2: 93.2 ms, 3: 92.9, 4: 76.2, 5: 69.5, 6: 77.0)
 #endif
+#ifndef RTX_F64_MIN_WAVES
+#define RTX_F64_MIN_WAVES 1   // double-precision instances (other than manifold NEE): the compiler's choice, 247 registers, 2 waves (1080p Cornell box, 32 spp: 32.5 ms; capped for 2 / 3 / 4 waves: 32.9 / 32.9 / 30.3, but the Whitted instance 19.5 -> 19.6 / 21.5 / 25.8)
+#endif
 #ifndef RTX_WHITTED_MIN_WAVES
 #define RTX_WHITTED_MIN_WAVES 6   // the single-precision Whitted instance (demo.json 2560 x 1440 x 256 spp: 3: 71.7 ms, 4: 64.8, 5: 65.6, 6: 55.3)
 #endif
@@ -81,7 +84,7 @@ template <class R> RTX_DEV const DMaterial<R>* stage_materials(const DScene<R>& 
 // 8 = NEE and MIS on, 16 = the pcg4d generator, 32 = no material has a normal map (the tangent-frame code is left out),
 // 64 = no emissive sphere.
 template <class R, int MODE, bool LDS_MATS, int INTEG = INTEG_PATH, int LEAN = 0>
-__global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4) ? RTX_MNEE_F32_MIN_WAVES : (MODE == MODE_FLAT ? (INTEG == INTEG_PATHPHOTON ? RTX_PHOTON_FLAT_MIN_WAVES : (LEAN & 1) ? RTX_LEAN_MIN_WAVES : (LEAN ? RTX_LEAN_ENV_MIN_WAVES : RTX_FLAT_MIN_WAVES)) : (INTEG == INTEG_PATH_MNEE ? RTX_MNEE_MIN_WAVES : (sizeof(R) == 4 ? (INTEG == INTEG_PATHPHOTON ? RTX_PHOTON_MIN_WAVES : INTEG == INTEG_WHITTED ? RTX_WHITTED_MIN_WAVES : RTX_TREE_MIN_WAVES) : 1)))) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
+__global__ __launch_bounds__(kBlock, (INTEG == INTEG_PATH_MNEE && sizeof(R) == 4) ? RTX_MNEE_F32_MIN_WAVES : (MODE == MODE_FLAT ? (INTEG == INTEG_PATHPHOTON ? RTX_PHOTON_FLAT_MIN_WAVES : (LEAN & 1) ? RTX_LEAN_MIN_WAVES : (LEAN ? RTX_LEAN_ENV_MIN_WAVES : RTX_FLAT_MIN_WAVES)) : (INTEG == INTEG_PATH_MNEE ? RTX_MNEE_MIN_WAVES : (sizeof(R) == 4 ? (INTEG == INTEG_PATHPHOTON ? RTX_PHOTON_MIN_WAVES : INTEG == INTEG_WHITTED ? RTX_WHITTED_MIN_WAVES : RTX_TREE_MIN_WAVES) : RTX_F64_MIN_WAVES)))) void render_fused_kernel(DScene<R> sc, DCamera<R> cam, DRenderParams P, R* __restrict__ partial,
                                                                DCounters* __restrict__ counters, int stack_first_int) {
   if constexpr ((LEAN & 1) != 0) { sc.env.valid = 0; sc.env.importance = 0; }
   if constexpr ((LEAN & 2) != 0) { sc.n_points = 0; sc.n_disks = 0; }
