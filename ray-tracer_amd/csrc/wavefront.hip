@@ -87,6 +87,11 @@ constexpr int kLeafBatch = RTX_LEAF_BATCH;
 #endif
 
 
+// The host reads the length of the ray queue every eighth turn (the kernels of the turns in between are enqueued without waiting),
+// every turn once the queue is short - and every turn while it is long: the streaming kernels' grids follow the last length read,
+// and a turn of millions of rays hides the round trip, where workgroups launched for entries that no longer exist would not be free
+// (10 M triangles, 1080p x 64 spp: 362.3 -> 360.3 ms).
+constexpr uint32_t kSyncEveryTurnAbove = 4u << 20;
 constexpr uint32_t kOverlapBelowSlots = 48u << 20;   // launches of fewer path slots run the two walks of a turn side by side (wavefront_render)
 #ifndef RTX_POOL_MULT
 #define RTX_POOL_MULT 256   // path slots per resident lane (180 B each: 24 GB at most on 256 CUs); 10 M triangles at 1080p x 64 spp (133 M work items of one sample): 16: 440 ms, 32: 409, 64: 389, 128: 374, 256 (every work item in flight): 364
@@ -315,7 +320,7 @@ RTX_DEV uint32_t feed_take(WaveFeed& f, uint32_t* cursor, bool want, uint32_t n)
 // How many lanes of a wave must be without a ray before it stops to hand out new ones (storing results, promoting the prefetched
 // rays and prefetching again costs the whole wave some sixty instructions).
 #ifndef RTX_REFILL_IDLE
-#define RTX_REFILL_IDLE 16   // 10 M triangles, 16 spp: 1: 207 ms, 8: 163, 16: 151, 32: 152
+#define RTX_REFILL_IDLE 24   // 10 M triangles, 16 spp: 1: 207 ms, 8: 163, 16: 151, 32: 152 (when the kernel was written); 1080p x 64 spp frame now: 8: 374.1 ms, 16: 362.2, 20: 360.1, 24: 358.7, 28: 360.0, 32: 364.1
 #endif
 
 template <int MODE>
@@ -743,7 +748,7 @@ int wavefront_render(WavefrontPool& pool, const DScene<float>& sc, const DCamera
   for (unsigned iter = 0;; ++iter) {
     const WfTurn turn = {(int)(iter & 1u), (int)((iter + 1u) & 1u), (int)(iter % 3u), (int)((iter + 1u) % 3u), (int)((iter + 2u) % 3u), (int)(iter & 1u)};
     run(&turn, grid);
-    if ((iter & 7u) == 7u || live_bound < 65536u) {
+    if ((iter & 7u) == 7u || live_bound < 65536u || live_bound > kSyncEveryTurnAbove) {
       uint32_t n_live = 0;
       if (hipMemcpyAsync(&n_live, &ctl->n_q_[turn.n_out].v, sizeof n_live, hipMemcpyDeviceToHost, stream) != hipSuccess ||
           hipStreamSynchronize(stream) != hipSuccess) { err = hipGetErrorString(hipGetLastError()); return RTX_ERR_HIP; }
