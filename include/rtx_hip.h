@@ -263,7 +263,7 @@ int rtx_render_wait(rtx_ctx* ctx, rtx_stats* stats);
  * hipFree, no allocating library routine): the chunk sums and counters of the render live in a 64 MiB array that is part of the
  * library's code object on every GPU (held until the process ends), and the kernels are the ones rtx_render_device launches,
  * so the film is the same bit for bit.  Limits, each refused with a message: single precision, RTX_MODE_PATHTRACE or
- * RTX_MODE_WHITTED, the fused pipeline (RTX_PIPELINE_AUTO must resolve to it: scenes of at most 12 bounded primitives; larger
+ * RTX_MODE_WHITTED, the fused pipeline (RTX_PIPELINE_AUTO must resolve to it: scenes of at most 1024 bounded primitives; larger
  * scenes with pipeline = RTX_PIPELINE_FUSED), use_mnee = 0, and
  * rows_of_shard * width * chunks * 12 bytes <= 64 MiB - 256, chunks = min(samples_per_pixel, 16) (e.g. 640x360 at any sample
  * count, 1920x1080 at 2 samples per pixel).  With stats = NULL the call only enqueues kernels on `hip_stream` (NULL = the context's

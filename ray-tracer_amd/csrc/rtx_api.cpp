@@ -65,6 +65,7 @@ using namespace rtx;
 // Samples and work items (pixel, sample chunk) a lane of a fused launch handles at least, which sizes the grid (see the launch in
 // render_enqueue).
 constexpr unsigned long long kFusedSamplesPerLane = 32, kFusedMinItemsPerLane = 3, kFusedRounds = 16;
+constexpr int kAutoQueuesAbovePrims = 1024;   // RTX_PIPELINE_AUTO: scenes of more bounded primitives take the queue pipeline (render_enqueue)
 constexpr int kWfTargetChunks = 64;   // chunks the queue pipeline cuts a pixel's sample sum into (render_enqueue); the fused kernels: 16
 constexpr size_t kScratchBytes = 64ull << 20;
 constexpr size_t kScratchHeader = 256;   // the counters, ahead of the chunk sums
@@ -721,11 +722,12 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
   const bool mnee = !whitted && !bdpt && !photon && s->use_mnee != 0 && s->use_nee != 0;
   const bool f64 = s->precision == RTX_PRECISION_F64;
   const bool f64_req = f64;
-  // AUTO: scenes that walk a tree run the queue-based pipeline (its traversal kernels hold 2-4x
-  // the waves of the fused kernel, measured 1.6x faster on a 10 M-triangle scene); scenes small
-  // enough for the linear / flat intersection stay fused (no queue traffic, measured 2-3x faster).
+  // AUTO: scenes of many bounded primitives run the queue-based pipeline (its traversal kernels hold twice the waves of the fused
+  // tree-walking kernel and keep their lanes full by refilling); small ones stay fused (no queue traffic).  Triangle soups at
+  // 1080p x 16 spp, fused / queues in ms: 30 triangles 10.0 / 27.2, 300: 19.5 / 28.6, 1000: 29.9 / 31.7, 2000: 38.3 / 34.8, 4000: 48.3 /
+  // 38.9, 10 000: 68.0 / 47.2, 100 000: 164 / 88, 1 M: 358 / 133 (scripts/pipeline_crossover.py).
   int pipeline = s->pipeline;
-  if (pipeline == RTX_PIPELINE_AUTO) pipeline = (!f64_req && !whitted && !bdpt && !photon && !mnee && c->scene.n_prims > kLinearMaxPrims) ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED;
+  if (pipeline == RTX_PIPELINE_AUTO) pipeline = (!f64_req && !whitted && !bdpt && !photon && !mnee && c->scene.n_prims > kAutoQueuesAbovePrims) ? RTX_PIPELINE_WAVEFRONT : RTX_PIPELINE_FUSED;
   if (pipeline == RTX_PIPELINE_WAVEFRONT) {
     // The queue pipeline cuts the sample sum finer: a path slot renders the samples of its work item one after the other, so the
     // number of turns (and with it the number of launches, each with a start and an end at which the device is not full) follows
