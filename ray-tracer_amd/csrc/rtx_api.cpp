@@ -833,8 +833,7 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     // per lane at the best): 1080p Cornell box 1024 spp 202.5 -> 168.4 (192; 128: 169.0, 384: 169.7); cornell_box_quad +
     // caustics_test 800 x 800 x 128 16.8 -> 14.5 (24; 48: 14.8); Cornell box 64 spp 15.5 -> 13.3 (24; 96: 14.2), 16 spp 4.94 -> 4.49
     // (12; 24: 4.65, 6: 5.44); double precision 32 spp 34.0 -> 32.0 (48); manifold NEE 16 spp 338.7 -> 317.2 (24); environment_demo
-    // 4K 256 spp 220.5 -> 186.6.  Whitted (uniform cost per pixel: 22.2 -> 22.3 at best) keeps the resident grid; BDPT and PathPhoton:
-    // below.  The film does not depend on the grid.
+    // 4K 256 spp 220.5 -> 186.6.  Whitted, BDPT and PathPhoton: below.  The film does not depend on the grid.
     const int blocks_per_cu = stack ? 3 : 6;
     const unsigned long long one_item_each = (items + kBlock - 1) / kBlock, resident = (unsigned long long)c->n_cus * blocks_per_cu;
     unsigned long long per_lane = 0ull;   // 0 = the resident grid
@@ -849,8 +848,13 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     } else {
       // PathPhoton: a sample costs many times a plain one (a density estimate per Lambertian vertex), a few per lane are enough:
       // 1080p Cornell box, 16 spp, resident grid 129.6 ms, 3 items per lane 102.7, 6: 102.8, 12: 104.2.  BDPT loses (its per-lane
-      // light-vertex store grows with the grid: 194.6 ms -> 199.4 at 3, 224.0 at 12) and keeps the resident grid, as Whitted does.
+      // light-vertex store grows with the grid: 194.6 ms -> 199.4 at 3, 224.0 at 12) and keeps the resident grid.
       if (photon) per_lane = 4ull;
+      // Whitted: with the instance at six waves per SIMD the resident grid (sized for three to six workgroups per CU) no longer
+      // fills the device, and short workgroups even out the glass regions here too.  Items per lane, 64 spp: demo.json 2560 x 1440
+      // resident grid 15.8 ms, 32: 17.9, 16: 13.1, 8: 12.4, 4: 13.6; earth_demo 4K 23.0 / 24: 19.9 / 16: 16.9 / 8: 18.3; kitchen_sink 4K
+      // 85.3 / 16: 80.1 / 8: 82.8.
+      if (whitted) per_lane = 16ull;
       if (const char* e = std::getenv("RTX_ITEMS_PER_LANE_MODES")) { const long v = std::atol(e); if (v >= 0 && v <= 4096) per_lane = (unsigned long long)v; }   // experiments
     }
     unsigned long long grid = std::min(one_item_each, resident);
