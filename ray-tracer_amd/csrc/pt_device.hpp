@@ -779,13 +779,27 @@ template <class R> RTX_DEV int cdf_bin(const R* cdf, int n_plus_1, R x) {
   return clampi(lo - 1, 0, n_plus_1 - 2);
 }
 
+// The same index, the bisection started between two entries of the function's guide (DEnv): x lies in [k / kEnvGuide,
+// (k + 1) / kEnvGuide), so the first element greater than x is neither before the first one greater than k / kEnvGuide nor after
+// the first one greater than (k + 1) / kEnvGuide.
+template <class R> RTX_DEV int cdf_bin_guided(const R* cdf, int n_plus_1, R x, const int32_t* guide) {
+  const int k = clampi((int)(x * R(kEnvGuide)), 0, kEnvGuide - 1);
+  int lo = guide[k], hi = guide[k + 1];
+  if (!(x >= R(0) && x < R(1))) { lo = 0; hi = n_plus_1; }   // (numbers outside [0, 1) take the whole row, as cdf_bin does)
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (cdf[mid] > x) hi = mid; else lo = mid + 1;
+  }
+  return clampi(lo - 1, 0, n_plus_1 - 2);
+}
+
 template <class R> RTX_DEV bool env_sample(const DEnv<R>& e, R u1, R u2, V3<R>& dir, V3<R>& Le, R& pdf) {
   if (!e.valid) return false;
-  int y = cdf_bin(e.marginal, e.h + 1, u1);
+  int y = cdf_bin_guided(e.marginal, e.h + 1, u1, e.marginal_guide);
   R mb = e.marginal[y], ma = e.marginal[y + 1];
   R row_t = (ma > mb) ? (u1 - mb) / (ma - mb) : R(0);
   const R* cond = e.conditional + (size_t)y * (e.w + 1);
-  int x = cdf_bin(cond, e.w + 1, u2);
+  int x = cdf_bin_guided(cond, e.w + 1, u2, e.conditional_guide + (size_t)y * (kEnvGuide + 1));
   R lo = cond[x], hi = cond[x + 1];
   R col_t = (hi > lo) ? (u2 - lo) / (hi - lo) : R(0);
   R u = (R(x) + col_t + R(0.5)) / R(e.w);   // half-texel shift relative to env_pdf's binning, as in the reference

@@ -264,6 +264,20 @@ template <class R> void fill_geometry(DScene<R>& sc, std::vector<DeviceBuffer>& 
     std::vector<R> mg(marginal.begin(), marginal.end()), cd(conditional.begin(), conditional.end());
     sc.env.texel = d_env_texels;
     sc.env.marginal = push(pool, mg, ok); sc.env.conditional = push(pool, cd, ok);
+    // guides (DEnv): from the values as the device holds them, compared as the device compares them
+    const int eh = d.environment->height, ew = d.environment->width;
+    auto guide = [](const R* cdf, int n_plus_1, int32_t* g) {
+      int i = 0;
+      for (int k = 0; k <= kEnvGuide; ++k) {
+        const R x = (R)k / (R)kEnvGuide;
+        while (i < n_plus_1 && !(cdf[i] > x)) ++i;   // first index with cdf[i] > x (the function does not decrease)
+        g[k] = i;
+      }
+    };
+    std::vector<int32_t> gm(kEnvGuide + 1), gc((size_t)eh * (kEnvGuide + 1));
+    guide(mg.data(), eh + 1, gm.data());
+    for (int y = 0; y < eh; ++y) guide(cd.data() + (size_t)y * (ew + 1), ew + 1, gc.data() + (size_t)y * (kEnvGuide + 1));
+    sc.env.marginal_guide = push(pool, gm, ok); sc.env.conditional_guide = push(pool, gc, ok);
     sc.env.w = d.environment->width; sc.env.h = d.environment->height;
     sc.env.intensity = (R)d.environment->intensity; sc.env.rotation = (R)d.environment->rotation;
     sc.env.valid = 1; sc.env.importance = env_total > 0.0 ? 1 : 0;   // ref: engine/texture.hpp:478-480, :692-694

@@ -78,10 +78,16 @@ constexpr int kMaxWalkLevels = 39;
 // (a,b,c) = outward normal, w = 0.
 struct alignas(16) DFlatRec { float a, b, c, w; int32_t mat, type, idx, pad; };
 
+// Guides of the importance sampler's two distribution functions: entry k = the first index whose value exceeds k / kEnvGuide, so a
+// number in [k / kEnvGuide, (k + 1) / kEnvGuide) has its upper bound between entries k and k + 1 and the bisection starts from there
+// instead of from the whole row (the same index, in three steps instead of ten).
+constexpr int kEnvGuide = 256;
 template <class R> struct DEnv {
   const float* texel;        // RGB, row 0 = top
   const R* marginal;         // h+1
   const R* conditional;      // h*(w+1)
+  const int32_t* marginal_guide;      // kEnvGuide + 1
+  const int32_t* conditional_guide;   // h * (kEnvGuide + 1)
   int32_t w, h;
   R intensity, rotation;
   int32_t valid, importance; // EnvironmentMap::valid() / has_importance_sampling()
