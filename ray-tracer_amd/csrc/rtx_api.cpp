@@ -733,9 +733,12 @@ static int render_enqueue(rtx_ctx* c, const rtx_settings* s, float* host_out, vo
     // number of turns (and with it the number of launches, each with a start and an end at which the device is not full) follows
     // the samples per item.  10 M triangles, 1080p, 64 spp, chunks of 4 / 2 / 1 samples: 389.9 / 371.5 / 373.9 ms; every 8th row of
     // that frame: 67.7 / 58.2 / 52.7 ms.  The pool holds the items of a 1080p frame at 32 spp at once; beyond, slots take new items
-    // as they finish theirs.  (Still a function of spp alone: films do not depend on shards or grids.  RTX_WF_CHUNKS: experiments.)
+    // as they finish theirs.  (Still a function of spp and the film's size alone: films do not depend on shards or grids.  RTX_WF_CHUNKS: experiments.)
     int target = kWfTargetChunks;
     if (const char* e = std::getenv("RTX_WF_CHUNKS")) target = std::max(1, std::atoi(e));
+    // (a launch indexes fewer than 2^31 work items: very large films fall back towards the fused kernels' 16 chunks - by the size
+    // of the whole film, which all shards of a frame share)
+    while (target > 16 && (unsigned long long)P.width * (unsigned long long)P.height * (unsigned long long)target >= 0x7fffffffull) target /= 2;
     target = std::min(P.spp, target);
     P.chunk_spp = (P.spp + target - 1) / target;
     P.n_chunks = (P.spp + P.chunk_spp - 1) / P.chunk_spp;

@@ -763,6 +763,24 @@ def test_postprocess_device_buffers_and_errors(pkg, oracle):
 SIZES = ((1, 1, 1, 1), (1, 1, 5000, 3), (65535, 1, 1, 2), (1, 4097, 2, 0), (33, 17, 17, 1), (7, 5, 3, 100000))
 
 
+def test_queue_pipeline_shard_of_a_very_large_film(pkg, tracer, load_scene):
+    """The queue pipeline cuts a pixel's samples into up to 64 chunks, and a launch indexes fewer than 2^31 (pixel, chunk) work
+    items: a film of more than 2^31 / 64 pixels takes fewer chunks (by the size of the whole film, so every shard of the frame
+    agrees) instead of being refused.  One row of a 65535 x 600 film (shard 0 of 600), as two different launches of the same rows."""
+    abi = pkg.abi
+    sd = load_scene("kitchen_sink")
+    pt = tracer(sd)
+    W, H, spp = 65535, 600, 64
+    pt.set_camera(sd.camera(W, H))
+    kw = dict(width=W, height=H, samples_per_pixel=spp, max_depth=4, seed=3, pipeline=abi.PIPELINE_WAVEFRONT, precision=abi.PRECISION_F32)
+    pt.set_settings(sd.settings(shard_index=0, shard_count=600, **kw))
+    row = pt.render().copy()
+    assert row.shape == (1, W, 3) and np.isfinite(row).all() and pt.last_stats.samples == W * spp
+    pt.set_settings(sd.settings(shard_index=0, shard_count=300, **kw))   # rows 0 and 300
+    two = pt.render()
+    assert two.shape == (2, W, 3) and np.array_equal(two[0].view(np.uint32), row[0].view(np.uint32))
+
+
 @pytest.mark.parametrize("name", ["cornell_box", "kitchen_sink", "normal_mapped", "environment_demo"])
 def test_corner_sizes_all_modes(name, pkg, tracer, load_scene):
     """Corner sizes through every mode, pipeline and precision: 1x1 films, one row of the maximum width, one column taller
